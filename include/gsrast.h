@@ -1,0 +1,131 @@
+/* gsrast.h — C ABI of libgsrast.so, the MI355X (gfx950) differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary of the hot path.  In the reference the boundary is the pybind11
+ * module `diff_gaussian_rasterization._C` of the un-vendored submodule (call site:
+ * gaussian_renderer/__init__.py:14,36-51,85-93; contract visible at train.py:106,129 and
+ * scene/gaussian_model.py:415-417).  Each entry point below names the `_C` function it replaces.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless the name ends in `_host`
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued on it
+ *   - optional inputs/outputs: NULL <=> not provided (the reference passes empty tensors)
+ *   - return value: 0 = ok, negative = gsr_status; message via gsr_last_error() (thread-local)
+ *   - the library holds no global mutable state; it is re-entrant (forward on the Python main
+ *     thread, backward on the autograd worker thread)
+ *   - all float tensors are contiguous fp32, layouts as at the reference call site:
+ *       means3D[P,3] shs[P,M,3] colors_precomp[P,3] opacities[P] scales[P,3] rotations[P,4]
+ *       cov3D_precomp[P,6] viewmatrix[4,4] projmatrix[4,4] (both already transposed, row-vector
+ *       convention: scene/cameras.py:54-56) campos[3] bg[3] out_color[3,H,W] radii[P] (int32)
+ */
+#ifndef GSRAST_H
+#define GSRAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_VERSION 1
+#define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
+                                       dconic A, B, C, dopacity, drgb[3], 3 pad) */
+
+typedef enum gsr_status {
+    GSR_OK = 0,
+    GSR_ERR_INVALID_ARGUMENT = -1,
+    GSR_ERR_HIP = -2,            /* a HIP runtime call or kernel launch failed */
+    GSR_ERR_PREFILTERED = -3,    /* prefiltered=1 but a Gaussian failed the frustum test (A.1) */
+    GSR_ERR_WORKSPACE = -4       /* workspace too small for this frame */
+} gsr_status;
+
+/* Per-call configuration = the scalar fields of GaussianRasterizationSettings
+ * (gaussian_renderer/__init__.py:36-49) plus the tile-row slab of multi-GPU sharding. */
+typedef struct gsr_frame_desc {
+    int32_t P;               /* number of Gaussians                                              */
+    int32_t sh_degree;       /* active SH degree D, 0..3                                          */
+    int32_t sh_coeffs;       /* M = stored coefficients per channel of shs[P,M,3]; 0 with colors */
+    int32_t width, height;   /* image_width, image_height                                        */
+    float tanfovx, tanfovy, scale_modifier;
+    int32_t prefiltered, debug;
+    int32_t tile_row_begin;  /* slab [tile_row_begin, tile_row_end) in 16-px tile rows;           */
+    int32_t tile_row_end;    /* tile_row_end <= 0 means "to the last row" (whole image: 0, 0)     */
+} gsr_frame_desc;
+
+typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */
+    const float *bg, *viewmatrix, *projmatrix, *campos;
+} gsr_camera;
+
+typedef struct gsr_gaussians {   /* arguments of GaussianRasterizer.forward (device) */
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+} gsr_gaussians;
+
+typedef struct gsr_grads {       /* outputs of the backward; any may be NULL (not wanted) */
+    float *means3D;        /* [P,3]   */
+    float *means2D;        /* [P,3]   (x, y) = dL/d(NDC position) incl. W/2, H/2; z = 0            */
+    float *shs;            /* [P,M,3] */
+    float *colors_precomp; /* [P,3]   */
+    float *opacities;      /* [P]     */
+    float *scales;         /* [P,3]   */
+    float *rotations;      /* [P,4]   */
+    float *cov3D_precomp;  /* [P,6]   */
+} gsr_grads;
+
+int gsr_version(void);
+const char *gsr_last_error(void);
+
+/* Sizes of the two frame-sized opaque workspaces (the reference's geomBuffer / imgBuffer, which
+ * `_C.rasterize_gaussians` allocates through its resize callback). */
+int gsr_workspace_sizes(const gsr_frame_desc *desc, size_t *geom_bytes, size_t *image_bytes);
+
+/* Size of the per-duplicate workspace (the reference's binningBuffer) for R = num_rendered. */
+int gsr_binning_size(const gsr_frame_desc *desc, int64_t num_rendered, size_t *binning_bytes);
+
+/* Stage 1 of `_C.rasterize_gaussians`: per-Gaussian preprocess (cull, project, EWA covariance,
+ * SH colour) + prefix sum of tiles touched.  Writes radii[P] and *num_rendered_host (the one
+ * host synchronisation of the path; it sizes the binning workspace). */
+int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g,
+                           void *geom_ws, int32_t *radii, int64_t *num_rendered_host, void *stream);
+
+/* Stage 2 of `_C.rasterize_gaussians`: duplicate-with-keys, radix tile-sort, tile ranges,
+ * per-tile front-to-back blend.  Rows of out_color outside the slab are left untouched. */
+int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *geom_ws, void *binning_ws,
+                       void *image_ws, int64_t num_rendered, float *out_color, void *stream);
+
+/* First half of `_C.rasterize_gaussians_backward`: reverse blend of the slab's tiles and the
+ * deterministic per-Gaussian reduction -> screen_grads[P, GSR_SCREEN_GRAD_STRIDE]. */
+int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const void *geom_ws, void *binning_ws,
+                        const void *image_ws, int64_t num_rendered, const float *dL_dcolor, float *screen_grads,
+                        void *stream);
+
+/* Second half of `_C.rasterize_gaussians_backward`: per-Gaussian backward (2D covariance, projection,
+ * SH, 3D covariance) for Gaussians [g_begin, g_end).  Every non-NULL output row in that range is
+ * written (zeros for invisible Gaussians and for SH coefficients above the active degree). */
+int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g,
+                      const int32_t *radii, const void *geom_ws, const float *screen_grads, int32_t g_begin,
+                      int32_t g_end, const gsr_grads *out, void *stream);
+
+/* `_C.mark_visible`: present[i] = 1 iff Gaussian i passes the near-plane test (A.1). */
+int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                     uint8_t *present, void *stream);
+
+/* Introspection for tests / profiling: copies of intermediate device arrays' ADDRESSES inside the
+ * workspaces (no data is copied).  Any out-pointer may be NULL. */
+typedef struct gsr_debug_views {
+    const float *splat_records;   /* [P,12]: x, y, conicA, conicB, conicC, opacity, r, g, b, depth, radius, 0 */
+    const uint32_t *tiles_touched; /* [P]  */
+    const uint32_t *point_offsets; /* [P] inclusive scan */
+    const uint8_t *clamped;        /* [P] bit c set <=> channel c clamped */
+    const uint64_t *sorted_keys;   /* [R]  */
+    const uint32_t *sorted_gaussian; /* [R] Gaussian index per sorted instance */
+    const uint32_t *ranges;        /* [Tn,2] */
+    const float *final_T;          /* [H*W] */
+    const int32_t *n_contrib;      /* [H*W] */
+} gsr_debug_views;
+int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws,
+                        const void *image_ws, int64_t num_rendered, gsr_debug_views *views);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRAST_H */

@@ -1,0 +1,176 @@
+// gsr_geom.hip — per-Gaussian kernels: forward preprocess (K1), geometry backward (K8+K9 fused),
+// frustum test (K10).  One thread per Gaussian; the maths lives in gsr_math.h.
+//
+// HBM traffic per Gaussian: K1 reads 44 + 12K B (means 12, scale 12, quat 16, opacity 4,
+// K SH triples) and writes 48 (record) + 4 (radii) + 4 (tiles) + 1 (clamp mask); K8+K9 reads
+// 48 (screen grads) + 44 + 12K + 5 and writes 40 + 12M.  Camera matrices are wave-uniform loads that
+// the compiler scalarises (s_load) — they never cost vector memory bandwidth.
+#include "gsr_internal.h"
+
+namespace gsr {
+
+constexpr int kGeomBlock = 256;
+
+template <int DEG>
+__global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float *__restrict__ view,
+                                                           const float *__restrict__ proj, const float *__restrict__ campos,
+                                                           const float *__restrict__ means, const float *__restrict__ scales,
+                                                           const float *__restrict__ rots, const float *__restrict__ covpre,
+                                                           const float *__restrict__ opac, const float *__restrict__ shs,
+                                                           const float *__restrict__ colpre, float4 *__restrict__ records,
+                                                           uint32_t *__restrict__ tiles, uint8_t *__restrict__ clamped,
+                                                           int32_t *__restrict__ radii)
+{
+    const int i = blockIdx.x * kGeomBlock + threadIdx.x;
+    if (i >= f.P) return;
+    float V[16], PV[16], cp[3];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
+    cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
+    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, cv[6];
+    if (covpre) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cv[k] = covpre[6 * (size_t)i + k];
+    } else {
+        sc[0] = scales[3 * i]; sc[1] = scales[3 * i + 1]; sc[2] = scales[3 * i + 2];
+        const float4 qq = reinterpret_cast<const float4 *>(rots)[i];
+        q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+    }
+    PreOut o;
+    preprocess_one<DEG>(f, V, PV, cp, p, sc, q, covpre ? cv : nullptr, opac[i], shs ? shs + (size_t)i * f.M * 3 : nullptr,
+                   colpre ? colpre + 3 * (size_t)i : nullptr, o);
+    radii[i] = o.radius;
+    tiles[i] = o.tiles;
+    clamped[i] = (uint8_t)o.clamped;
+    records[3 * (size_t)i + 0] = make_float4(o.s.x, o.s.y, o.s.cA, o.s.cB);
+    records[3 * (size_t)i + 1] = make_float4(o.s.cC, o.s.op, o.s.r, o.s.g);
+    records[3 * (size_t)i + 2] = make_float4(o.s.b, o.s.depth, o.s.radius, 0.f);
+}
+
+int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
+                      bool debug, hipStream_t s)
+{
+    if (f.P == 0) return GSR_OK;
+    const int grid = (f.P + kGeomBlock - 1) / kGeomBlock;
+#define GSR_PRE(DEG)                                                                                              \
+    hipLaunchKernelGGL(k_preprocess<DEG>, dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
+                       cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs,         \
+                       g.colors_precomp, ws.records, ws.tiles_touched, ws.clamped, radii)
+    switch (g.shs ? f.D : 0) {
+        case 0: GSR_PRE(0); break;
+        case 1: GSR_PRE(1); break;
+        case 2: GSR_PRE(2); break;
+        default: GSR_PRE(3); break;
+    }
+#undef GSR_PRE
+    GSR_LAUNCH_CHECK("preprocess", debug, s);
+    return GSR_OK;
+}
+
+// ---- K8 + K9: dL/d(screen-space quantities) -> dL/d(inputs) for Gaussians [g0, g1).
+template <int DEG>
+__global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g1, const float *__restrict__ view,
+                                                         const float *__restrict__ proj, const float *__restrict__ campos,
+                                                         const float *__restrict__ means, const float *__restrict__ scales,
+                                                         const float *__restrict__ rots, const float *__restrict__ covpre,
+                                                         const float *__restrict__ shs, int has_colpre,
+                                                         const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
+                                                         const float4 *__restrict__ screen, gsr_grads out)
+{
+    const int i = g0 + blockIdx.x * kGeomBlock + threadIdx.x;
+    if (i >= g1) return;
+    const int M = f.M;
+    const bool visible = radii[i] > 0;
+    GeomGrad g;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { g.dmean[k] = 0.f; g.dcolor[k] = 0.f; g.dscale[k] = 0.f; }
+    g.dmean2D[0] = g.dmean2D[1] = 0.f; g.dopacity = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g.drot[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) g.dcov[k] = 0.f;
+    float dsh[48];
+    const int K = (DEG + 1) * (DEG + 1);
+    if (visible) {
+        float V[16], PV[16], cp[3];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
+        cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
+        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, cv[6];
+        if (covpre) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cv[k] = covpre[6 * (size_t)i + k];
+        } else {
+            sc[0] = scales[3 * i]; sc[1] = scales[3 * i + 1]; sc[2] = scales[3 * i + 2];
+            const float4 qq = reinterpret_cast<const float4 *>(rots)[i];
+            q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+        }
+        const float4 s0 = screen[3 * (size_t)i], s1 = screen[3 * (size_t)i + 1], s2 = screen[3 * (size_t)i + 2];
+        const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
+        geom_backward_one<DEG>(f, V, PV, cp, p, sc, q, covpre ? cv : nullptr, shs ? shs + (size_t)i * M * 3 : nullptr,
+                          has_colpre != 0, clamped[i], sg, g, (shs && out.shs) ? dsh : nullptr);
+    }
+    if (out.means3D) { out.means3D[3 * i] = g.dmean[0]; out.means3D[3 * i + 1] = g.dmean[1]; out.means3D[3 * i + 2] = g.dmean[2]; }
+    if (out.means2D) { out.means2D[3 * i] = g.dmean2D[0]; out.means2D[3 * i + 1] = g.dmean2D[1]; out.means2D[3 * i + 2] = 0.f; }
+    if (out.opacities) out.opacities[i] = g.dopacity;
+    if (out.colors_precomp && has_colpre) {
+        out.colors_precomp[3 * i] = g.dcolor[0]; out.colors_precomp[3 * i + 1] = g.dcolor[1]; out.colors_precomp[3 * i + 2] = g.dcolor[2];
+    }
+    if (out.scales && !covpre) { out.scales[3 * i] = g.dscale[0]; out.scales[3 * i + 1] = g.dscale[1]; out.scales[3 * i + 2] = g.dscale[2]; }
+    if (out.rotations && !covpre) reinterpret_cast<float4 *>(out.rotations)[i] = make_float4(g.drot[0], g.drot[1], g.drot[2], g.drot[3]);
+    if (out.cov3D_precomp && covpre) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out.cov3D_precomp[6 * (size_t)i + k] = g.dcov[k];
+    }
+    if (out.shs && shs) {
+        float *dst = out.shs + (size_t)i * M * 3;
+        const int live = visible ? 3 * K : 0;
+#pragma unroll
+        for (int k = 0; k < 48; ++k)
+            if (k < 3 * M) dst[k] = k < live ? dsh[k] : 0.f;
+    }
+}
+
+int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
+                    const float *screen_grads, int g0, int g1, const gsr_grads &out, bool debug, hipStream_t s)
+{
+    if (g1 <= g0) return GSR_OK;
+    const int grid = (g1 - g0 + kGeomBlock - 1) / kGeomBlock;
+#define GSR_GB(DEG)                                                                                               \
+    hipLaunchKernelGGL(k_geom_bwd<DEG>, dim3(grid), dim3(kGeomBlock), 0, s, f, g0, g1, cam.viewmatrix, cam.projmatrix, \
+                       cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.shs, g.colors_precomp ? 1 : 0, \
+                       radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads), out)
+    switch (g.shs ? f.D : 0) {
+        case 0: GSR_GB(0); break;
+        case 1: GSR_GB(1); break;
+        case 2: GSR_GB(2); break;
+        default: GSR_GB(3); break;
+    }
+#undef GSR_GB
+    GSR_LAUNCH_CHECK("geom_bwd", debug, s);
+    return GSR_OK;
+}
+
+__global__ __launch_bounds__(kGeomBlock) void k_mark_visible(int P, const float *__restrict__ means,
+                                                             const float *__restrict__ view, uint8_t *__restrict__ present)
+{
+    const int i = blockIdx.x * kGeomBlock + threadIdx.x;
+    if (i >= P) return;
+    float V[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) V[k] = view[k];
+    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    present[i] = in_frustum(p, V) ? 1 : 0;
+}
+
+int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s)
+{
+    if (P == 0) return GSR_OK;
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + kGeomBlock - 1) / kGeomBlock), dim3(kGeomBlock), 0, s, P, means3D, view, present);
+    GSR_LAUNCH_CHECK("mark_visible", false, s);
+    return GSR_OK;
+}
+
+}  // namespace gsr

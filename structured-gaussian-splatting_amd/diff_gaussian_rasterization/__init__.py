@@ -1,0 +1,243 @@
+"""Drop-in for the reference's `diff_gaussian_rasterization` package, MI355X-native.
+
+Public surface = what the reference imports and calls (gaussian_renderer/__init__.py:14,36-51,85-93):
+
+    GaussianRasterizationSettings(image_height, image_width, tanfovx, tanfovy, bg, scale_modifier,
+                                  viewmatrix, projmatrix, sh_degree, campos, prefiltered, debug)
+    GaussianRasterizer(raster_settings).forward(means3D, means2D, opacities, shs=None, colors_precomp=None,
+                                                scales=None, rotations=None, cov3D_precomp=None)
+        -> (color[3,H,W] float32, radii[P] int32)
+    GaussianRasterizer.markVisible(positions) -> bool[P]
+
+Autograd contract (train.py:106, scene/gaussian_model.py:415-417): gradients for
+(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, None) in that order;
+`means2D.grad[:, :2]` is dL/d(NDC position) with the W/2, H/2 pixel scale folded in, `[:, 2] = 0`.
+
+Everything below the autograd.Function is the C ABI of libgsrast.so (include/gsrast.h): hand-written
+gfx950 HIP kernels.  There is no CPU path — missing library => RuntimeError at first use.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+from torch import nn
+
+from . import _native as N
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _f32c(t: Optional[torch.Tensor], device=None) -> Optional[torch.Tensor]:
+    """Contiguous fp32 view/copy on `device`, or None for missing / empty tensors (the reference passes
+    empty tensors for absent optionals; callers may hand in non-contiguous or detached views:
+    scene/latent_gaussian_model.py:193-199, scene/gaussian_model.py:104-125)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    if device is not None and t.device != device:
+        raise ValueError(f"tensor on {t.device}, rasterizer inputs live on {device}")
+    return t.contiguous()
+
+
+class _Frame:
+    """Native handles of one forward pass, kept alive by autograd's ctx for the backward."""
+    __slots__ = ("desc", "cam", "keep", "R", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device")
+
+
+def _camera(rs: GaussianRasterizationSettings, device):
+    bg, vm, pm, cp = (_f32c(rs.bg, device), _f32c(rs.viewmatrix, device), _f32c(rs.projmatrix, device),
+                      _f32c(rs.campos, device))
+    if bg is None or vm is None or pm is None or cp is None:
+        raise ValueError("bg, viewmatrix, projmatrix and campos must be non-empty device tensors")
+    return N.Camera(N._ptr(bg), N._ptr(vm), N._ptr(pm), N._ptr(cp)), (bg, vm, pm, cp)
+
+
+def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                      rs: GaussianRasterizationSettings, tile_rows=None, out_color=None):
+    """Stage 1 + stage 2 of the native forward.  Returns (color, radii, frame)."""
+    device = means3D.device
+    if device.type != "cuda":
+        raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a HIP device; "
+                           "there is no CPU path")
+    P = int(means3D.shape[0])
+    H, W = int(rs.image_height), int(rs.image_width)
+    means3D = _f32c(means3D, device)
+    sh, colors_precomp = _f32c(sh, device), _f32c(colors_precomp, device)
+    opacities = _f32c(opacities, device)
+    scales, rotations, cov3D_precomp = _f32c(scales, device), _f32c(rotations, device), _f32c(cov3D_precomp, device)
+    M = int(sh.shape[1]) if sh is not None else 0
+    fr = _Frame()
+    fr.device, fr.M = device, M
+    fr.desc = N.make_desc(P, int(rs.sh_degree), M, W, H, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.prefiltered,
+                          rs.debug, tile_rows)
+    fr.cam, cam_keep = _camera(rs, device)
+    fr.gauss = N.Gaussians(N._ptr(means3D), N._ptr(sh), N._ptr(colors_precomp), N._ptr(opacities), N._ptr(scales),
+                           N._ptr(rotations), N._ptr(cov3D_precomp))
+    fr.keep = (cam_keep, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+    geom_bytes, image_bytes = N.workspace_sizes(fr.desc)
+    fr.geom_ws = torch.empty(geom_bytes, dtype=torch.uint8, device=device)
+    fr.image_ws = torch.empty(image_bytes, dtype=torch.uint8, device=device)
+    fr.radii = torch.zeros(P, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        fr.R = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device)
+        fr.binning_ws = torch.empty(N.binning_size(fr.desc, fr.R), dtype=torch.uint8, device=device)
+        color = out_color if out_color is not None else torch.zeros(3, H, W, dtype=torch.float32, device=device)
+        N.forward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.R, color, device)
+    return color, fr.radii, fr
+
+
+def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.Tensor:
+    """K7 + deterministic per-Gaussian reduction -> screen-space gradients [P, 12]."""
+    P = fr.desc.P
+    grad_color = _f32c(grad_color, fr.device)
+    screen = torch.empty(max(P, 1), N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=fr.device)
+    if grad_color is None:
+        return screen.zero_()[:P]
+    with torch.cuda.device(fr.device):
+        N.backward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.R, grad_color, screen, fr.device)
+    return screen[:P]
+
+
+def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int = 0, g1: Optional[int] = None):
+    """K8 + K9 on Gaussians [g0, g1).  `needs` = (means3D, means2D, sh, colors, opacities, scales, rotations,
+    cov3D) booleans.  Returns the 8 gradient tensors (None where not needed / not applicable)."""
+    P, M, dev = fr.desc.P, fr.M, fr.device
+    g1 = P if g1 is None else g1
+    (_, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp) = fr.keep
+    partial = (g0, g1) != (0, P)
+    alloc = torch.zeros if partial else torch.empty
+
+    def mk(flag, present, *shape):
+        return alloc(*shape, dtype=torch.float32, device=dev) if (flag and present) else None
+    g_means3D = mk(needs[0], True, P, 3)
+    g_means2D = mk(needs[1], True, P, 3)
+    g_sh = mk(needs[2], sh is not None, P, M, 3)
+    g_col = mk(needs[3], colors_precomp is not None, P, 3)
+    g_op = mk(needs[4], True, P, 1)
+    g_sc = mk(needs[5], scales is not None, P, 3)
+    g_rot = mk(needs[6], rotations is not None, P, 4)
+    g_cov = mk(needs[7], cov3D_precomp is not None, P, 6)
+    grads = N.Grads(N._ptr(g_means3D), N._ptr(g_means2D), N._ptr(g_sh), N._ptr(g_col), N._ptr(g_op), N._ptr(g_sc),
+                    N._ptr(g_rot), N._ptr(g_cov))
+    if P > 0 and g1 > g0:
+        with torch.cuda.device(dev):
+            N.backward_geom(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, g0, g1, grads, dev)
+    return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov
+
+
+def _dump(path, payload):
+    try:
+        torch.save(payload, path)
+    except Exception:      # the dump is a debugging aid; never mask the original error
+        pass
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        args = (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+        if rs.debug:
+            cpu_args = tuple(a.detach().cpu().clone() for a in args)      # README.md:147-150 semantics
+            try:
+                color, radii, frame = rasterize_forward(*args, rs)
+                torch.cuda.synchronize(means3D.device)
+            except Exception:
+                _dump("snapshot_fw.dump", (cpu_args, tuple(rs)))
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise
+        else:
+            color, radii, frame = rasterize_forward(*args, rs)
+        ctx.frame = frame
+        ctx.raster_settings = rs
+        ctx.shapes = (means2D.shape, opacities.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        fr, rs = ctx.frame, ctx.raster_settings
+        needs = tuple(ctx.needs_input_grad[:8])
+        # input order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp
+        order = (needs[0], needs[1], needs[2], needs[3], needs[4], needs[5], needs[6], needs[7])
+
+        def run():
+            screen = rasterize_backward_screen(fr, grad_out_color)
+            return rasterize_backward_geom(fr, screen, order)
+        if rs.debug:
+            try:
+                out = run()
+                torch.cuda.synchronize(fr.device)
+            except Exception:
+                _dump("snapshot_bw.dump", (tuple(None if k is None else k.detach().cpu() for k in fr.keep[1:]),
+                                           grad_out_color.detach().cpu(), tuple(rs)))
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
+        else:
+            out = run()
+        g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov = out
+        if g_op is not None:
+            g_op = g_op.view(ctx.shapes[1])
+        if g_means2D is not None:
+            g_means2D = g_means2D.view(ctx.shapes[0])
+        ctx.frame = None
+        return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """Frustum test per point (the reference's `_C.mark_visible`; unused in-tree, kept for API parity)."""
+        rs = self.raster_settings
+        with torch.no_grad():
+            pos = _f32c(positions, positions.device)
+            present = torch.zeros(positions.shape[0], dtype=torch.uint8, device=positions.device)
+            if pos is not None:
+                vm, pm = _f32c(rs.viewmatrix, positions.device), _f32c(rs.projmatrix, positions.device)
+                with torch.cuda.device(positions.device):
+                    N.mark_visible(pos, vm, pm, present)
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        empty = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        rs = rs._replace(sh_degree=int(rs.sh_degree), image_height=int(rs.image_height),
+                         image_width=int(rs.image_width))
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)

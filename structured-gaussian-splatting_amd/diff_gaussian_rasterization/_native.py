@@ -1,0 +1,173 @@
+"""ctypes binding of libgsrast.so (C ABI: include/gsrast.h).
+
+There is NO fallback: if the HIP library is missing or a call fails, this module raises.  The product
+path never imports the CPU oracle (oracle/ is test infrastructure).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libgsrast.so")
+_CSRC = os.path.join(_PKG_ROOT, "csrc")
+SCREEN_GRAD_STRIDE = 12
+
+_f32p = C.c_void_p
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("P", C.c_int32), ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+                ("prefiltered", C.c_int32), ("debug", C.c_int32), ("tile_row_begin", C.c_int32),
+                ("tile_row_end", C.c_int32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("bg", _f32p), ("viewmatrix", _f32p), ("projmatrix", _f32p), ("campos", _f32p)]
+
+
+class Gaussians(C.Structure):
+    _fields_ = [("means3D", _f32p), ("shs", _f32p), ("colors_precomp", _f32p), ("opacities", _f32p),
+                ("scales", _f32p), ("rotations", _f32p), ("cov3D_precomp", _f32p)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("means3D", _f32p), ("means2D", _f32p), ("shs", _f32p), ("colors_precomp", _f32p),
+                ("opacities", _f32p), ("scales", _f32p), ("rotations", _f32p), ("cov3D_precomp", _f32p)]
+
+
+class DebugViews(C.Structure):
+    _fields_ = [("splat_records", C.c_void_p), ("tiles_touched", C.c_void_p), ("point_offsets", C.c_void_p),
+                ("clamped", C.c_void_p), ("sorted_keys", C.c_void_p), ("sorted_gaussian", C.c_void_p),
+                ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p)]
+
+
+EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
+           "gsr_forward_render", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views")
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def build(force: bool = False) -> str:
+    """Compile libgsrast.so for gfx950 with hipcc (csrc/Makefile).  Cross-compiles without a GPU."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", _CSRC, "-j4"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"libgsrast.so not found at {_LIB_PATH}: the HIP extension is required (no CPU fallback exists). "
+                f"Build it with `make -C {_CSRC}` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+        lib = C.CDLL(_LIB_PATH)
+        lib.gsr_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            if not hasattr(lib, name):
+                raise RuntimeError(f"libgsrast.so does not export {name}")
+        _lib = lib
+    return _lib
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().gsr_last_error().decode("utf-8", "replace")
+        raise GsrError(f"{what} failed (status {rc}): {msg}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    if t is None or t.numel() == 0:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def make_desc(P, sh_degree, sh_coeffs, width, height, tanfovx, tanfovy, scale_modifier, prefiltered, debug,
+              tile_rows=None) -> FrameDesc:
+    ty0, ty1 = (0, 0) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+    return FrameDesc(int(P), int(sh_degree), int(sh_coeffs), int(width), int(height), float(tanfovx), float(tanfovy),
+                     float(scale_modifier), int(bool(prefiltered)), int(bool(debug)), ty0, ty1)
+
+
+def workspace_sizes(desc: FrameDesc):
+    g, i = C.c_size_t(0), C.c_size_t(0)
+    _check(load().gsr_workspace_sizes(C.byref(desc), C.byref(g), C.byref(i)), "gsr_workspace_sizes")
+    return g.value, i.value
+
+
+def binning_size(desc: FrameDesc, R: int) -> int:
+    b = C.c_size_t(0)
+    _check(load().gsr_binning_size(C.byref(desc), C.c_int64(R), C.byref(b)), "gsr_binning_size")
+    return b.value
+
+
+def forward_preprocess(desc, cam: Camera, g: Gaussians, geom_ws, radii, device) -> int:
+    R = C.c_int64(0)
+    _check(load().gsr_forward_preprocess(C.byref(desc), C.byref(cam), C.byref(g), _ptr(geom_ws), _ptr(radii),
+                                         C.byref(R), _stream(device)), "gsr_forward_preprocess")
+    return int(R.value)
+
+
+def forward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, R, out_color, device):
+    _check(load().gsr_forward_render(C.byref(desc), C.byref(cam), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws),
+                                     C.c_int64(R), _ptr(out_color), _stream(device)), "gsr_forward_render")
+
+
+def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, R, dL_dcolor, screen_grads, device):
+    _check(load().gsr_backward_render(C.byref(desc), C.byref(cam), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws),
+                                      C.c_int64(R), _ptr(dL_dcolor), _ptr(screen_grads), _stream(device)),
+           "gsr_backward_render")
+
+
+def backward_geom(desc, cam: Camera, g: Gaussians, radii, geom_ws, screen_grads, g0, g1, grads: Grads, device):
+    _check(load().gsr_backward_geom(C.byref(desc), C.byref(cam), C.byref(g), _ptr(radii), _ptr(geom_ws),
+                                    _ptr(screen_grads), C.c_int32(g0), C.c_int32(g1), C.byref(grads), _stream(device)),
+           "gsr_backward_geom")
+
+
+def mark_visible(means3D, viewmatrix, projmatrix, present):
+    _check(load().gsr_mark_visible(C.c_int32(means3D.shape[0]), _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix),
+                                   _ptr(present), _stream(means3D.device)), "gsr_mark_visible")
+
+
+def debug_views(desc, geom_ws, binning_ws, image_ws, R) -> dict:
+    """Intermediate arrays as torch views INTO the workspaces (tests / profiling)."""
+    v = DebugViews()
+    _check(load().gsr_debug_get_views(C.byref(desc), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws), C.c_int64(R),
+                                      C.byref(v)), "gsr_debug_get_views")
+    P, N = desc.P, desc.width * desc.height
+    Tn = ((desc.width + 15) // 16) * ((desc.height + 15) // 16)
+
+    def view(ws, addr, nbytes, dtype, shape):
+        if not addr or ws is None:
+            return None
+        off = addr - ws.data_ptr()
+        return ws[off:off + nbytes].view(dtype).view(shape)
+    return dict(
+        splat_records=view(geom_ws, v.splat_records, P * 48, torch.float32, (P, 12)),
+        tiles_touched=view(geom_ws, v.tiles_touched, P * 4, torch.int32, (P,)),
+        point_offsets=view(geom_ws, v.point_offsets, P * 4, torch.int32, (P,)),
+        clamped=view(geom_ws, v.clamped, P, torch.uint8, (P,)),
+        sorted_gaussian=view(binning_ws, v.sorted_gaussian, R * 4, torch.int32, (R,)) if R else None,
+        ranges=view(image_ws, v.ranges, Tn * 8, torch.int32, (Tn, 2)),
+        final_T=view(image_ws, v.final_T, N * 4, torch.float32, (desc.height, desc.width)),
+        n_contrib=view(image_ws, v.n_contrib, N * 4, torch.int32, (desc.height, desc.width)))

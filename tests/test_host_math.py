@@ -1,0 +1,115 @@
+"""CPU check of the product's per-Gaussian maths header (csrc/gsr_math.h — the functions the HIP
+preprocess / geometry-backward kernels wrap) against the oracle, via a g++-compiled test harness
+(tests/host_harness.cpp).  Host-logic coverage for `-m "not gpu"`; the kernels themselves are
+checked on the GPU in test_gpu_parity.py.
+"""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import scene_synth as S
+from util import cov3d_from, raster_kwargs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hh(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("hh") / "libhost_harness.so")
+    subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so, os.path.join(HERE, "host_harness.cpp")])
+    return C.CDLL(so)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, np.float32)
+
+
+def _run(hh, kw, slab=(0, 0)):
+    P = kw["means3D"].shape[0]
+    shs = _f32(kw.get("shs")); M = 0 if shs is None else shs.shape[1]
+    W, H, D = kw["image_width"], kw["image_height"], kw["sh_degree"]
+    V, PV, cam = _f32(kw["viewmatrix"]), _f32(kw["projmatrix"]), _f32(kw["campos"])
+    means, sc, ro = _f32(kw["means3D"]), _f32(kw.get("scales")), _f32(kw.get("rotations"))
+    cp, op, col = _f32(kw.get("cov3D_precomp")), _f32(kw["opacities"]).reshape(-1), _f32(kw.get("colors_precomp"))
+    radii = np.zeros(P, np.int32); tiles = np.zeros(P, np.uint32); cl = np.zeros(P, np.uint8); rec = np.zeros((P, 12), np.float32)
+    hh.hh_preprocess(P, D, M, W, H, C.c_float(kw["tanfovx"]), C.c_float(kw["tanfovy"]), C.c_float(kw["scale_modifier"]),
+                     slab[0], slab[1], _p(V), _p(PV), _p(cam), _p(means), _p(sc), _p(ro), _p(cp), _p(op), _p(shs), _p(col),
+                     _p(radii), _p(tiles), _p(cl), _p(rec))
+    return dict(radii=radii, tiles=tiles, clamped=cl, rec=rec, args=(P, D, M, W, H, V, PV, cam, means, sc, ro, cp, shs, col))
+
+
+@pytest.mark.parametrize("mode", ["sh+scale", "color+cov"])
+@pytest.mark.parametrize("D", [0, 3])
+def test_preprocess_matches_oracle(hh, mode, D):
+    scene, cam = S.make_scene(3000, 160, 112, D, 41 + D, scale_lo=0.005, scale_hi=0.08), S.make_camera(160, 112)
+    a = scene.activated()
+    extra = {}
+    if mode == "color+cov":
+        extra = dict(colors_precomp=torch.rand(scene.P, 3, generator=torch.Generator().manual_seed(1)),
+                     cov3D_precomp=cov3d_from(a["scales"], a["rotations"]))
+    kw = raster_kwargs(scene, cam, **extra)
+    fr = oracle.rasterize(dtype=np.float32, **kw)
+    got = _run(hh, kw)
+    np.testing.assert_array_equal(got["radii"], fr.radii)
+    np.testing.assert_array_equal(got["tiles"], fr.tiles_touched)
+    vis = fr.radii > 0
+    assert vis.sum() > 1000
+    rec = got["rec"][vis]
+    np.testing.assert_allclose(rec[:, 0:2], fr.xy[vis], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(rec[:, 2:5], fr.conic_opacity[vis, :3], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(rec[:, 5], fr.conic_opacity[vis, 3], rtol=0, atol=0)
+    np.testing.assert_allclose(rec[:, 6:9], fr.rgb[vis], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rec[:, 9], fr.depth[vis], rtol=1e-6)
+    bits = (fr.clamped[:, 0] | (fr.clamped[:, 1] << 1) | (fr.clamped[:, 2] << 2)).astype(np.uint8)
+    np.testing.assert_array_equal(got["clamped"][vis], bits[vis])
+    # slab clipping only changes the tile count
+    slab = _run(hh, kw, slab=(2, 5))
+    frs = oracle.rasterize(dtype=np.float32, tile_rows=(2, 5), **kw)
+    np.testing.assert_array_equal(slab["tiles"], frs.tiles_touched)
+    np.testing.assert_array_equal(slab["radii"], fr.radii)
+
+
+@pytest.mark.parametrize("mode", ["sh+scale", "color+cov"])
+def test_geom_backward_matches_oracle(hh, mode):
+    D = 3
+    scene, cam = S.make_scene(2000, 128, 96, D, 77, scale_lo=0.005, scale_hi=0.08), S.make_camera(128, 96)
+    a = scene.activated()
+    extra = {}
+    if mode == "color+cov":
+        extra = dict(colors_precomp=torch.rand(scene.P, 3, generator=torch.Generator().manual_seed(1)),
+                     cov3D_precomp=cov3d_from(a["scales"], a["rotations"]))
+    kw = raster_kwargs(scene, cam, **extra)
+    fr = oracle.rasterize(dtype=np.float64, **kw)
+    gimg = S.make_grad_image(128, 96, 5).numpy()
+    want = fr.backward(gimg)
+    got_f = _run(hh, kw)
+    P, D, M, W, H, V, PV, camc, means, sc, ro, cp, shs, col = got_f["args"]
+    screen = np.ascontiguousarray(want["screen"], np.float32)
+    out = dict(means3D=np.zeros((P, 3), np.float32), means2D=np.zeros((P, 3), np.float32),
+               shs=np.zeros((P, max(M, 1), 3), np.float32), colors_precomp=np.zeros((P, 3), np.float32),
+               opacities=np.zeros(P, np.float32), scales=np.zeros((P, 3), np.float32),
+               rotations=np.zeros((P, 4), np.float32), cov3D_precomp=np.zeros((P, 6), np.float32))
+    hh.hh_geom_backward(P, D, M, W, H, C.c_float(kw["tanfovx"]), C.c_float(kw["tanfovy"]), C.c_float(1.0), _p(V), _p(PV),
+                        _p(camc), _p(means), _p(sc), _p(ro), _p(cp), _p(shs), int(col is not None), _p(got_f["radii"]),
+                        _p(got_f["clamped"]), _p(screen), _p(out["means3D"]), _p(out["means2D"]), _p(out["shs"]),
+                        _p(out["colors_precomp"]), _p(out["opacities"]), _p(out["scales"]), _p(out["rotations"]),
+                        _p(out["cov3D_precomp"]))
+    names = ["means3D", "means2D", "opacities"] + (["colors_precomp", "cov3D_precomp"] if mode == "color+cov" else ["shs", "scales", "rotations"])
+    for n in names:
+        w = want[n].reshape(out[n].shape) if n != "shs" else want[n]
+        g = out[n] if n != "shs" else out[n][:, :M]
+        scale = np.abs(w).max()
+        assert scale > 0, n
+        # fp32 evaluation of a cancellation-prone chain: 1e-4 of the tensor's scale, 2e-3 relative per element
+        err = np.abs(g - w)
+        assert (err <= 1e-4 * scale + 2e-3 * np.abs(w)).all(), f"{n}: max err {err.max():.3e} scale {scale:.3e}"
