@@ -162,7 +162,7 @@ def test_intermediates_bit_exact_vs_oracle_f32():
         assert bad.size < 1e-3 * got.size
     vis = fr.radii > 0
     np.testing.assert_allclose(rec[vis, 0:2], fr.xy[vis], rtol=1e-6, atol=2e-4)
-    np.testing.assert_allclose(rec[vis, 2:5], fr.conic_opacity[vis, :3], rtol=3e-5, atol=1e-7)
+    np.testing.assert_allclose(rec[vis, 2:5], fr.conic_opacity[vis, :3], rtol=3e-5, atol=2e-6)   # B cancels to ~0
     np.testing.assert_allclose(rec[vis, 6:9], fr.rgb[vis], rtol=1e-5, atol=2e-6)
     nc = v["n_contrib"].cpu().numpy()
     strict = fr.fragile_px == 0
