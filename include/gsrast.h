@@ -125,6 +125,15 @@ typedef struct gsr_debug_views {
 int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws,
                         const void *image_ws, int64_t num_rendered, gsr_debug_views *views);
 
+/* Per-kernel device timing (hipEvent pairs recorded on the caller's stream around every kernel this
+ * library launches, from any thread).  Off by default; the only process-wide state of the library,
+ * mutex-protected, meant for benchmarks (one frame in flight).  gsr_profile_enable(1) resets the
+ * accumulators.  gsr_profile_read synchronises the recorded events and returns up to `max_entries`
+ * (name, total milliseconds, launch count) rows; returns the number of rows written. */
+#define GSR_PROFILE_NAME_LEN 32
+int gsr_profile_enable(int enable);
+int gsr_profile_read(int max_entries, char (*names)[GSR_PROFILE_NAME_LEN], float *total_ms, int32_t *launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 #include "gsr_internal.h"
 
 namespace gsr {
@@ -15,6 +18,62 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+}
+
+// ---- per-kernel timing: process-wide (the backward runs on the autograd worker thread) list of
+// (name, start, stop) event pairs behind a mutex; events pooled.  Opt-in, off by default.
+struct ProfEntry { char name[GSR_PROFILE_NAME_LEN]; hipEvent_t a, b; };
+struct ProfState {
+    bool on = false;
+    std::vector<ProfEntry> pending;
+    std::vector<hipEvent_t> pool;
+    struct Acc { char name[GSR_PROFILE_NAME_LEN]; double ms; int n; };
+    std::vector<Acc> acc;
+};
+static ProfState g_prof;
+static std::mutex g_prof_mu;
+
+bool profile_on() { return g_prof.on; }
+
+static hipEvent_t prof_event()
+{
+    if (!g_prof.pool.empty()) { hipEvent_t e = g_prof.pool.back(); g_prof.pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int profile_begin(const char *name, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfEntry e;
+    strncpy(e.name, name, GSR_PROFILE_NAME_LEN - 1);
+    e.name[GSR_PROFILE_NAME_LEN - 1] = 0;
+    e.a = prof_event(); e.b = prof_event();
+    (void)hipEventRecord(e.a, s);
+    g_prof.pending.push_back(e);
+    return (int)g_prof.pending.size() - 1;
+}
+
+void profile_end(int idx, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (idx >= 0 && idx < (int)g_prof.pending.size()) (void)hipEventRecord(g_prof.pending[idx].b, s);
+}
+
+static void profile_drain()
+{
+    for (auto &e : g_prof.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            bool found = false;
+            for (auto &a : g_prof.acc)
+                if (!strcmp(a.name, e.name)) { a.ms += ms; a.n += 1; found = true; break; }
+            if (!found) { ProfState::Acc a; strcpy(a.name, e.name); a.ms = ms; a.n = 1; g_prof.acc.push_back(a); }
+        }
+        g_prof.pool.push_back(e.a); g_prof.pool.push_back(e.b);
+    }
+    g_prof.pending.clear();
 }
 
 static int validate(const gsr_frame_desc *d)
@@ -173,6 +232,30 @@ int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, c
     (void)projmatrix;
     if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) { set_error("gsr_mark_visible: bad argument"); return GSR_ERR_INVALID_ARGUMENT; }
     return launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+int gsr_profile_enable(int enable)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    profile_drain();
+    g_prof.acc.clear();
+    g_prof.on = enable != 0;
+    return GSR_OK;
+}
+
+int gsr_profile_read(int max_entries, char (*names)[GSR_PROFILE_NAME_LEN], float *total_ms, int32_t *launches)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    profile_drain();
+    int n = 0;
+    for (auto &a : g_prof.acc) {
+        if (n >= max_entries) break;
+        if (names) strcpy(names[n], a.name);
+        if (total_ms) total_ms[n] = (float)a.ms;
+        if (launches) launches[n] = a.n;
+        ++n;
+    }
+    return n;
 }
 
 int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws, const void *image_ws,

@@ -88,6 +88,7 @@ int launch_scan(GeomWS &ws, int P, bool debug, hipStream_t s)
 {
     if (P == 0) return GSR_OK;
     size_t bytes = ws.scan_temp_bytes;
+    ProfileScope prof("scan", s);
     GSR_HIP_CHECK(rocprim::inclusive_scan(ws.scan_temp, bytes, ws.tiles_touched, ws.offsets, (size_t)P,
                                           rocprim::plus<uint32_t>(), s));
     GSR_LAUNCH_CHECK("scan", debug, s);
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(kBinBlock) void k_duplicate(FrameK f, const float4 
 int launch_duplicate(const FrameK &f, const GeomWS &gw, BinningWS &bw, int64_t R, bool debug, hipStream_t s)
 {
     if (f.P == 0 || R == 0) return GSR_OK;
+    ProfileScope prof("duplicate", s);
     hipLaunchKernelGGL(k_duplicate, dim3((f.P + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, s, f, gw.records,
                        gw.tiles_touched, gw.offsets, bw.keys[0], bw.vals[0], bw.inst_gid);
     GSR_LAUNCH_CHECK("duplicate", debug, s);
@@ -147,6 +149,7 @@ int launch_sort(const FrameK &f, BinningWS &bw, int64_t R, int *result_buffer, b
     rocprim::double_buffer<uint64_t> k(bw.keys[0], bw.keys[1]);
     rocprim::double_buffer<uint32_t> v(bw.vals[0], bw.vals[1]);
     size_t bytes = bw.sort_temp_bytes;
+    ProfileScope prof("radix_sort", s);
     GSR_HIP_CHECK(rocprim::radix_sort_pairs(bw.sort_temp, bytes, k, v, (size_t)R, 0, (unsigned)end_bit, s));
     *result_buffer = (k.current() == bw.keys[0]) ? 0 : 1;
     GSR_LAUNCH_CHECK("radix_sort", debug, s);
@@ -178,6 +181,7 @@ int launch_ranges(const FrameK &f, BinningWS &bw, int result_buffer, ImageWS &iw
     const size_t Tn = (size_t)f.Gx * f.Gy;
     GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, Tn * sizeof(uint2), s));
     if (R == 0) return GSR_OK;
+    ProfileScope prof("ranges", s);
     hipLaunchKernelGGL(k_ranges, dim3((unsigned)((R + kBinBlock - 1) / kBinBlock)), dim3(kBinBlock), 0, s, R,
                        bw.keys[result_buffer], bw.vals[result_buffer], bw.inst_gid, iw.ranges, bw.sorted_gid,
                        bw.sorted_slot);

@@ -53,6 +53,7 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 {
     if (f.P == 0) return GSR_OK;
     const int grid = (f.P + kGeomBlock - 1) / kGeomBlock;
+    ProfileScope prof("preprocess", s);
 #define GSR_PRE(DEG)                                                                                              \
     hipLaunchKernelGGL(k_preprocess<DEG>, dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
                        cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs,         \
@@ -138,6 +139,7 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
 {
     if (g1 <= g0) return GSR_OK;
     const int grid = (g1 - g0 + kGeomBlock - 1) / kGeomBlock;
+    ProfileScope prof("geom_bwd", s);
 #define GSR_GB(DEG)                                                                                               \
     hipLaunchKernelGGL(k_geom_bwd<DEG>, dim3(grid), dim3(kGeomBlock), 0, s, f, g0, g1, cam.viewmatrix, cam.projmatrix, \
                        cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.shs, g.colors_precomp ? 1 : 0, \

@@ -38,6 +38,16 @@ void set_error(const char *fmt, ...);     // thread-local message behind gsr_las
         }                                                                                         \
     } while (0)
 
+// ---- optional per-kernel timing (gsr_profile_enable / gsr_profile_read)
+bool profile_on();
+int profile_begin(const char *name, hipStream_t s);
+void profile_end(int idx, hipStream_t s);
+struct ProfileScope {
+    hipStream_t s; int idx;
+    ProfileScope(const char *name, hipStream_t st) : s(st), idx(profile_on() ? profile_begin(name, st) : -1) {}
+    ~ProfileScope() { if (idx >= 0) profile_end(idx, s); }
+};
+
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
 inline FrameK make_frame(const gsr_frame_desc &d)

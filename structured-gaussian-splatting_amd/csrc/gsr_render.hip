@@ -144,6 +144,7 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, const GeomWS &gw, 
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0) return GSR_OK;
+    ProfileScope prof("render_fwd", s);
     hipLaunchKernelGGL(k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, iw.ranges, bw.sorted_gid, gw.records,
                        cam.bg, out_color, iw.final_T, iw.n_contrib);
     GSR_LAUNCH_CHECK("render_fwd", debug, s);
@@ -282,6 +283,7 @@ int launch_render_bwd(const FrameK &f, const gsr_camera &cam, const GeomWS &gw, 
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0) return GSR_OK;
+    ProfileScope prof("render_bwd", s);
     hipLaunchKernelGGL(k_render_bwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, iw.ranges, bw.sorted_gid, bw.sorted_slot,
                        gw.records, cam.bg, iw.final_T, iw.n_contrib, dL_dcolor, reinterpret_cast<float4 *>(bw.grad_rows));
     GSR_LAUNCH_CHECK("render_bwd", debug, s);
@@ -317,6 +319,7 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int P, const uint32_t
 int launch_reduce_rows(const FrameK &f, const GeomWS &gw, const BinningWS &bw, float *screen_grads, bool debug, hipStream_t s)
 {
     if (f.P == 0) return GSR_OK;
+    ProfileScope prof("reduce_rows", s);
     hipLaunchKernelGGL(k_reduce_rows, dim3((f.P + kRedBlock - 1) / kRedBlock), dim3(kRedBlock), 0, s, f.P, gw.tiles_touched,
                        gw.offsets, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads));
     GSR_LAUNCH_CHECK("reduce_rows", debug, s);

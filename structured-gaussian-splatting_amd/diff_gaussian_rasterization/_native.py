@@ -48,7 +48,8 @@ class DebugViews(C.Structure):
 
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
-           "gsr_forward_render", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views")
+           "gsr_forward_render", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
+           "gsr_profile_read")
 
 _lib = None
 
@@ -171,3 +172,18 @@ def debug_views(desc, geom_ws, binning_ws, image_ws, R) -> dict:
         ranges=view(image_ws, v.ranges, Tn * 8, torch.int32, (Tn, 2)),
         final_T=view(image_ws, v.final_T, N * 4, torch.float32, (desc.height, desc.width)),
         n_contrib=view(image_ws, v.n_contrib, N * 4, torch.int32, (desc.height, desc.width)))
+
+
+def profile_enable(on: bool):
+    """Per-kernel hipEvent timing inside the library (thread-local; resets the accumulators)."""
+    _check(load().gsr_profile_enable(C.c_int(int(on))), "gsr_profile_enable")
+
+
+def profile_read() -> dict:
+    """{kernel name: (total_ms, launches)} since profile_enable(True); synchronises the recorded events."""
+    n_max = 32
+    names = ((C.c_char * 32) * n_max)()
+    ms = (C.c_float * n_max)()
+    cnt = (C.c_int32 * n_max)()
+    n = load().gsr_profile_read(n_max, names, ms, cnt)
+    return {names[i].value.decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}

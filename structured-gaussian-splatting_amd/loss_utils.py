@@ -1,0 +1,52 @@
+"""The loss of the reference's timed training window (train.py:104-105): L1 and D-SSIM, plus PSNR.
+Host-side mirror of utils/loss_utils.py:17-63 and utils/image_utils.py:14-19 in plain torch (these run
+unmodified on ROCm); pinned by tests/golden/loss.npz."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def l1_loss(network_output, gt):
+    return torch.abs(network_output - gt).mean()
+
+
+def l2_loss(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+def _window(size: int, channel: int, sigma: float = 1.5) -> torch.Tensor:
+    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(size)])
+    g = (g / g.sum()).unsqueeze(1)
+    w2 = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, size, size).contiguous()
+
+
+_WINDOWS = {}
+
+
+def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
+    channel = img1.size(-3)
+    key = (window_size, channel, img1.device, img1.dtype)
+    if key not in _WINDOWS:
+        _WINDOWS[key] = _window(window_size, channel).to(device=img1.device, dtype=img1.dtype)
+    w, pad = _WINDOWS[key], window_size // 2
+    mu1 = F.conv2d(img1, w, padding=pad, groups=channel)
+    mu2 = F.conv2d(img2, w, padding=pad, groups=channel)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = F.conv2d(img1 * img1, w, padding=pad, groups=channel) - mu1_sq
+    s2 = F.conv2d(img2 * img2, w, padding=pad, groups=channel) - mu2_sq
+    s12 = F.conv2d(img1 * img2, w, padding=pad, groups=channel) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return m.mean() if size_average else m.mean(1).mean(1).mean(1)
+
+
+def training_loss(image, gt, lambda_dssim: float = 0.2):
+    """(1 - lambda) L1 + lambda (1 - SSIM), train.py:104-105 with arguments/__init__.py:89's default."""
+    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
+def psnr(img1, img2):
+    mse = ((img1 - img2) ** 2).view(img1.shape[0], -1).mean(1, keepdim=True)
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
