@@ -1,0 +1,225 @@
+"""Multi-GPU rasterization by tile-row slabs — one process per GPU, torch.distributed
+over RCCL/xGMI ("nccl" backend on ROCm).
+
+The reference has no distributed code; this is net-new.  Partitioning:
+
+  * image: contiguous slabs of 16-px tile rows, one per rank; Gaussian parameters replicated.
+    Every rank runs the per-Gaussian preprocess for all P (cheap, no exchange), bins and blends only the
+    tiles of its slab (gsr_frame_desc.tile_row_begin/end).
+  * forward exchange: ALL-GATHER of the rendered slabs -> full image on every rank (the loss needs an
+    11x11 SSIM window across slab borders).
+  * backward exchange: REDUCE-SCATTER (sum) of the per-Gaussian SCREEN-SPACE gradients
+    (12 floats / Gaussian, 9 used: the small choice (ii) of SURVEY 8e), then the per-Gaussian geometry
+    backward runs on each rank's 1/world shard of the Gaussians, then ALL-GATHER of the parameter gradients.
+
+xGMI is point-to-point: per-GPU messages are kept large and few (one collective per direction per
+tensor); sizes at P = 1e6: slabs 24.9 MB total, screen grads 48 MB, parameter grads 236 MB.
+
+`backend` is the compute provider: the native HIP library by default (fails loudly if missing).  Tests
+inject a CPU provider to exercise this file's partitioning/collective logic under gloo.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+SCREEN_STRIDE = 12
+
+
+def slab_bounds(tile_rows: int, world: int, weights: Optional[List[float]] = None) -> List[Tuple[int, int]]:
+    """Split tile rows [0, tile_rows) into `world` contiguous slabs.  Without weights: as even as possible.
+    With per-tile-row weights (e.g. splat instances per row): boundaries at equal cumulative weight
+    (SURVEY 7 "slab load balance").  Slabs may be empty when world > tile_rows."""
+    if weights is None:
+        base, rem = divmod(tile_rows, world)
+        out, y = [], 0
+        for r in range(world):
+            n = base + (1 if r < rem else 0)
+            out.append((y, y + n))
+            y += n
+        return out
+    assert len(weights) == tile_rows
+    cum, acc = [], 0.0
+    for w in weights:
+        acc += float(w)
+        cum.append(acc)
+    total = acc or 1.0
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        y = bounds[-1]
+        while y < tile_rows and cum[y] <= target:
+            y += 1
+        bounds.append(min(max(y, bounds[-1]), tile_rows))
+    bounds.append(tile_rows)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def gaussian_shard(P: int, world: int, rank: int) -> Tuple[int, int, int]:
+    """Rank's Gaussian range [g0, g1) and the padded shard length (equal on all ranks)."""
+    shard = (P + world - 1) // world
+    g0 = min(rank * shard, P)
+    return g0, min(g0 + shard, P), shard
+
+
+class NativeBackend:
+    """Compute provider = libgsrast.so through the drop-in package (the product path)."""
+
+    def forward(self, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, tile_rows, out_color):
+        from . import rasterize_forward
+        return rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs,
+                                 tile_rows=tile_rows, out_color=out_color)
+
+    def backward_screen(self, frame, grad_color):
+        from . import rasterize_backward_screen
+        return rasterize_backward_screen(frame, grad_color)
+
+    def backward_geom(self, frame, screen, needs, g0, g1):
+        from . import rasterize_backward_geom
+        return rasterize_backward_geom(frame, screen, needs, g0, g1)
+
+
+class _Comm:
+    """The three collectives of the path, with a gloo-compatible form for the CPU tests."""
+
+    def __init__(self, dist, world, rank, group=None):
+        self.dist, self.world, self.rank, self.group = dist, world, rank, group
+        self.native_rs = dist.get_backend(group) != "gloo"
+
+    def all_gather(self, shard: torch.Tensor) -> torch.Tensor:
+        """[n, ...] per rank -> [world * n, ...]."""
+        out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        self.dist.all_gather_into_tensor(out, shard.contiguous(), group=self.group)
+        return out
+
+    def reduce_scatter_sum(self, full: torch.Tensor) -> torch.Tensor:
+        """[world * n, ...] per rank -> [n, ...] = sum over ranks of this rank's block."""
+        n = full.shape[0] // self.world
+        if self.native_rs:
+            out = torch.empty((n,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
+            self.dist.reduce_scatter_tensor(out, full.contiguous(), op=self.dist.ReduceOp.SUM, group=self.group)
+            return out
+        full = full.contiguous().clone()            # gloo has no reduce_scatter: all_reduce + slice (tests only)
+        self.dist.all_reduce(full, op=self.dist.ReduceOp.SUM, group=self.group)
+        return full[self.rank * n:(self.rank + 1) * n].clone()
+
+
+class _ShardedRasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, shard):
+        comm, backend = shard.comm, shard.backend
+        H, W = int(rs.image_height), int(rs.image_width)
+        Gy = (H + 15) // 16
+        slabs = shard.slabs(Gy)
+        ty0, ty1 = slabs[comm.rank]
+        rows_max = max(min(b * 16, H) - min(a * 16, H) for a, b in slabs)
+        # render own slab into a padded [3, rows_max, W] buffer positioned at image row 0 of the buffer
+        full = torch.zeros(3, H, W, dtype=means3D.dtype, device=means3D.device)
+        color, radii, frame = backend.forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                              rs, (ty0, ty1) if ty1 > ty0 else (Gy, Gy), full)
+        y0, y1 = min(ty0 * 16, H), min(ty1 * 16, H)
+        mine = torch.zeros(1, 3, rows_max, W, dtype=full.dtype, device=full.device)
+        if y1 > y0:
+            mine[0, :, :y1 - y0] = full[:, y0:y1]
+        gathered = comm.all_gather(mine)                        # [world, 3, rows_max, W]
+        for r, (a, b) in enumerate(slabs):
+            a_px, b_px = min(a * 16, H), min(b * 16, H)
+            if b_px > a_px and r != comm.rank:
+                full[:, a_px:b_px] = gathered[r, :, :b_px - a_px]
+        ctx.frame, ctx.shard, ctx.rs = frame, shard, rs
+        ctx.shapes = (means2D.shape, opacities.shape)
+        ctx.mark_non_differentiable(radii)
+        return full, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _):
+        frame, shard = ctx.frame, ctx.shard
+        comm, backend = shard.comm, shard.backend
+        P = frame.desc.P if hasattr(frame, "desc") else frame.P
+        needs = tuple(ctx.needs_input_grad[:8])
+        g0, g1, slen = gaussian_shard(P, comm.world, comm.rank)
+        # (1) my slab's contribution to every Gaussian's screen-space gradient
+        partial = backend.backward_screen(frame, grad_color)                       # [P, 12]
+        padded = torch.zeros(comm.world * slen, SCREEN_STRIDE, dtype=partial.dtype, device=partial.device)
+        padded[:P] = partial
+        # (2) sum over slabs, scattered by Gaussian shard
+        mine = comm.reduce_scatter_sum(padded)                                     # [slen, 12]
+        screen = torch.zeros(max(P, 1), SCREEN_STRIDE, dtype=partial.dtype, device=partial.device)
+        if g1 > g0:
+            screen[g0:g1] = mine[:g1 - g0]
+        # (3) geometry backward on my shard, (4) all-gather of the parameter gradients
+        grads = backend.backward_geom(frame, screen[:P], needs, g0, g1)
+        out = []
+        for g in grads:
+            if g is None:
+                out.append(None)
+                continue
+            blk = torch.zeros((slen,) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            if g1 > g0:
+                blk[:g1 - g0] = g[g0:g1]
+            out.append(comm.all_gather(blk)[:P])
+        g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov = out
+        if g_op is not None:
+            g_op = g_op.reshape(ctx.shapes[1])
+        if g_means2D is not None:
+            g_means2D = g_means2D.reshape(ctx.shapes[0])
+        ctx.frame = None
+        return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None, None
+
+
+class ShardedRenderer:
+    """render()-shaped front end for world_size > 1 (same arguments and returned dict as
+    gaussian_renderer.render, reference gaussian_renderer/__init__.py:18-100)."""
+
+    def __init__(self, dist, world: int, rank: int, backend=None, group=None, row_weights=None):
+        self.comm = _Comm(dist, world, rank, group)
+        self.backend = NativeBackend() if backend is None else backend
+        self.row_weights = row_weights
+
+    def slabs(self, Gy: int):
+        return slab_bounds(Gy, self.comm.world, self.row_weights if self.row_weights and len(self.row_weights) == Gy else None)
+
+    def rasterize(self, rs, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                  cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = torch.empty(0, dtype=torch.float32, device=means3D.device)
+        rs = rs._replace(sh_degree=int(rs.sh_degree))
+        return _ShardedRasterize.apply(means3D, means2D, e if shs is None else shs,
+                                       e if colors_precomp is None else colors_precomp, opacities,
+                                       e if scales is None else scales, e if rotations is None else rotations,
+                                       e if cov3D_precomp is None else cov3D_precomp, rs, self)
+
+    def render(self, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
+        import math
+
+        from . import GaussianRasterizationSettings
+        xyz = pc.get_xyz
+        screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
+        try:
+            screenspace_points.retain_grad()
+        except Exception:
+            pass
+        rs = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+            tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+            scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+            projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+            campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+        scales = rotations = cov = None
+        if pipe.compute_cov3D_python:
+            cov = pc.get_covariance(scaling_modifier)
+        else:
+            scales, rotations = pc.get_scaling, pc.get_rotation
+        shs = colors = None
+        if override_color is None:
+            shs = pc.get_features
+        else:
+            colors = override_color
+        image, radii = self.rasterize(rs, xyz, screenspace_points, pc.get_opacity, shs=shs, colors_precomp=colors,
+                                      scales=scales, rotations=rotations, cov3D_precomp=cov)
+        return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}

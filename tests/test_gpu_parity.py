@@ -313,3 +313,37 @@ def test_cfg3_full_size_properties():
     scale = s12.abs().max()
     assert (s12 - (s1 + 2 * s2)).abs().max() <= 1e-4 * scale
     assert int((radii > 0).sum()) > 500_000
+
+
+def test_sharded_renderer_native_backend_world1():
+    """ShardedRenderer with the native HIP backend over RCCL ("nccl"), world_size 1 on the one GPU of this
+    box: exercises slab render -> all-gather -> reduce-scatter -> sharded geometry backward -> all-gather
+    end to end on device tensors; must equal the plain render() bit for bit (forward) / to rounding."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+    from diff_gaussian_rasterization.sharded import ShardedRenderer
+    from gaussian_params import GaussianParams, Pipe
+    from gaussian_renderer import render
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        scene, cam = S.make_scene(20000, 320, 200, 3, 301, scale_lo=0.005, scale_hi=0.06), S.make_camera(320, 200)
+        cam = cam.to(DEV)
+        bg = torch.tensor([0.1, 0.2, 0.3], device=DEV)
+        gimg = S.make_grad_image(320, 200, 1).to(DEV)
+        res = []
+        for mode in ("plain", "sharded"):
+            model = GaussianParams(scene.to(DEV)).to(DEV)
+            out = render(cam, model, Pipe(), bg) if mode == "plain" else ShardedRenderer(dist, 1, 0).render(cam, model, Pipe(), bg)
+            out["render"].backward(gimg)
+            res.append((out["render"].detach().clone(), out["radii"].clone(), out["viewspace_points"].grad.clone(),
+                        [p.grad.clone() for p in model.parameters()]))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert torch.equal(res[0][2], res[1][2])
+        for a, b in zip(res[0][3], res[1][3]):
+            assert torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
