@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 1
+#define GSR_VERSION 2
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -51,6 +51,25 @@ typedef struct gsr_frame_desc {
     int32_t tile_row_begin;  /* slab [tile_row_begin, tile_row_end) in 16-px tile rows;           */
     int32_t tile_row_end;    /* tile_row_end <= 0 means "to the last row" (whole image: 0, 0)     */
 } gsr_frame_desc;
+
+/* Host-side plan of one frame, written by gsr_forward_preprocess and handed to the later stages (the
+ * library itself keeps no per-frame state).  The forward is PROGRESSIVE: visible Gaussians are sorted by
+ * depth once, split into up to GSR_MAX_CHUNKS depth chunks, and each chunk is binned and blended only
+ * into tiles that still have an unsaturated pixel; a tile whose 256 pixels have all hit the
+ * transmittance cut-off (A.8) takes no further instances.  Pixels are identical to binning everything. */
+#define GSR_MAX_CHUNKS 8
+typedef struct gsr_frame_plan {
+    int64_t num_rendered;                         /* R: sum of (slab-clipped) tiles touched = the reference's
+                                                     num_rendered; upper bound of the instances emitted      */
+    int32_t num_visible;                          /* V: Gaussians with radius > 0                           */
+    int32_t num_chunks;                           /* depth chunks planned (1..GSR_MAX_CHUNKS)               */
+    int32_t chunk_rank_begin[GSR_MAX_CHUNKS + 1]; /* chunk c = depth ranks [begin[c], begin[c+1])           */
+    int64_t chunk_instances_max[GSR_MAX_CHUNKS];  /* instances of chunk c if every tile were open           */
+    int32_t chunks_run;                           /* out of gsr_forward_render: chunks actually processed   */
+    int32_t sort_result;                          /* out of gsr_forward_render: radix buffer holding lists  */
+    int64_t instances_emitted;                    /* out of gsr_forward_render: instances actually binned;
+                                                     -1 when the last chunk ran (its count is not read back)  */
+} gsr_frame_plan;
 
 typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */
     const float *bg, *viewmatrix, *projmatrix, *campos;
@@ -82,21 +101,24 @@ int gsr_workspace_sizes(const gsr_frame_desc *desc, size_t *geom_bytes, size_t *
 int gsr_binning_size(const gsr_frame_desc *desc, int64_t num_rendered, size_t *binning_bytes);
 
 /* Stage 1 of `_C.rasterize_gaussians`: per-Gaussian preprocess (cull, project, EWA covariance,
- * SH colour) + prefix sum of tiles touched.  Writes radii[P] and *num_rendered_host (the one
- * host synchronisation of the path; it sizes the binning workspace). */
+ * SH colour), depth sort of the Gaussians, prefix sum of tiles touched in depth order, chunk plan.
+ * Writes radii[P] and *plan_host (one host synchronisation; plan->num_rendered sizes the binning
+ * workspace). */
 int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g,
-                           void *geom_ws, int32_t *radii, int64_t *num_rendered_host, void *stream);
+                           void *geom_ws, int32_t *radii, gsr_frame_plan *plan_host, void *stream);
 
-/* Stage 2 of `_C.rasterize_gaussians`: duplicate-with-keys, radix tile-sort, tile ranges,
- * per-tile front-to-back blend.  Rows of out_color outside the slab are left untouched. */
+/* Stage 2 of `_C.rasterize_gaussians`: per depth chunk — emit (tile, instance) pairs into open tiles,
+ * stable radix sort by tile, tile ranges, per-tile front-to-back blend continuing each pixel's state.
+ * Stops as soon as no tile is open (one 4-byte readback per chunk).  Updates plan_host->chunks_run /
+ * instances_emitted.  Rows of out_color outside the slab are left untouched. */
 int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *geom_ws, void *binning_ws,
-                       void *image_ws, int64_t num_rendered, float *out_color, void *stream);
+                       void *image_ws, gsr_frame_plan *plan_host, float *out_color, void *stream);
 
 /* First half of `_C.rasterize_gaussians_backward`: reverse blend of the slab's tiles and the
  * deterministic per-Gaussian reduction -> screen_grads[P, GSR_SCREEN_GRAD_STRIDE]. */
 int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const void *geom_ws, void *binning_ws,
-                        const void *image_ws, int64_t num_rendered, const float *dL_dcolor, float *screen_grads,
-                        void *stream);
+                        const void *image_ws, const gsr_frame_plan *plan_host, const float *dL_dcolor,
+                        float *screen_grads, void *stream);
 
 /* Second half of `_C.rasterize_gaussians_backward`: per-Gaussian backward (2D covariance, projection,
  * SH, 3D covariance) for Gaussians [g_begin, g_end).  Every non-NULL output row in that range is
@@ -113,17 +135,17 @@ int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, c
  * workspaces (no data is copied).  Any out-pointer may be NULL. */
 typedef struct gsr_debug_views {
     const float *splat_records;   /* [P,12]: x, y, conicA, conicB, conicC, opacity, r, g, b, depth, radius, 0 */
-    const uint32_t *tiles_touched; /* [P]  */
-    const uint32_t *point_offsets; /* [P] inclusive scan */
-    const uint8_t *clamped;        /* [P] bit c set <=> channel c clamped */
-    const uint64_t *sorted_keys;   /* [R]  */
-    const uint32_t *sorted_gaussian; /* [R] Gaussian index per sorted instance */
-    const uint32_t *ranges;        /* [Tn,2] */
-    const float *final_T;          /* [H*W] */
-    const int32_t *n_contrib;      /* [H*W] */
+    const uint32_t *tiles_touched; /* [P]  by Gaussian */
+    const uint32_t *depth_order;   /* [P]  depth rank -> Gaussian (invisible ones last)                   */
+    const uint32_t *point_offsets; /* [P]  inclusive scan of tiles touched, in depth order               */
+    const uint8_t *clamped;        /* [P]  bit c set <=> channel c clamped */
+    const uint32_t *sorted_gaussian; /* [<=R] Gaussian index per binned instance (chunks concatenated)   */
+    const uint32_t *ranges;        /* [GSR_MAX_CHUNKS, Tn, 2] absolute [start, end) per chunk and tile   */
+    const float *final_T;          /* [H*W] (negative sign marks a pixel that hit the cut-off)           */
+    const int32_t *n_contrib;      /* [H*W] encoded: (chunk + 1) << 26 | position in that chunk's range  */
 } gsr_debug_views;
 int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws,
-                        const void *image_ws, int64_t num_rendered, gsr_debug_views *views);
+                        const void *image_ws, const gsr_frame_plan *plan_host, gsr_debug_views *views);
 
 /* Per-kernel device timing (hipEvent pairs recorded on the caller's stream around every kernel this
  * library launches, from any thread).  Off by default; the only process-wide state of the library,

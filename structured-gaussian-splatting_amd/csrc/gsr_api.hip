@@ -142,59 +142,95 @@ int gsr_binning_size(const gsr_frame_desc *desc, int64_t num_rendered, size_t *b
 }
 
 int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws,
-                           int32_t *radii, int64_t *num_rendered_host, void *stream)
+                           int32_t *radii, gsr_frame_plan *plan, void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
     if ((rc = validate_inputs(desc, cam, g))) return rc;
-    if (!num_rendered_host || (desc->P > 0 && (!geom_ws || !radii))) { set_error("NULL output"); return GSR_ERR_INVALID_ARGUMENT; }
+    if (!plan || (desc->P > 0 && (!geom_ws || !radii))) { set_error("NULL output"); return GSR_ERR_INVALID_ARGUMENT; }
     hipStream_t s = (hipStream_t)stream;
+    const bool dbg = desc->debug != 0;
     const FrameK f = make_frame(*desc);
-    *num_rendered_host = 0;
+    memset(plan, 0, sizeof *plan);
+    plan->num_chunks = 1;
     if (f.P == 0) return GSR_OK;
     GeomWS gw = carve_geom(geom_ws, f.P);
-    if ((rc = launch_preprocess(f, *cam, *g, gw, radii, desc->debug != 0, s))) return rc;
-    if ((rc = launch_scan(gw, f.P, desc->debug != 0, s))) return rc;
-    // The one host synchronisation of the path: R sizes the binning workspace.
-    uint32_t total = 0;
-    GSR_HIP_CHECK(hipMemcpyAsync(&total, gw.offsets + (f.P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if ((rc = launch_preprocess(f, *cam, *g, gw, radii, dbg, s))) return rc;
+    if ((rc = launch_depth_order(f, gw, dbg, s))) return rc;
+    if ((rc = launch_chunk_plan(f, gw, dbg, s))) return rc;
+    // The one host synchronisation of this stage: the plan (R sizes the binning workspace).
+    Ctrl h;
+    GSR_HIP_CHECK(hipMemcpyAsync(&h, gw.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
     GSR_HIP_CHECK(hipStreamSynchronize(s));
-    *num_rendered_host = (int64_t)total;
+    plan->num_rendered = (int64_t)h.R_total;
+    plan->num_visible = (int32_t)h.V;
+    plan->num_chunks = h.num_chunks > 0 ? (int32_t)h.num_chunks : 1;
+    for (int c = 0; c <= GSR_MAX_CHUNKS; ++c) plan->chunk_rank_begin[c] = (int32_t)h.bnd[c];
+    for (int c = 0; c < GSR_MAX_CHUNKS; ++c) plan->chunk_instances_max[c] = (int64_t)h.chunk_full[c];
+    if (h.num_chunks == 0)
+        for (int c = 0; c <= GSR_MAX_CHUNKS; ++c) plan->chunk_rank_begin[c] = 0;
     return GSR_OK;
 }
 
 int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *geom_ws, void *binning_ws, void *image_ws,
-                       int64_t num_rendered, float *out_color, void *stream)
+                       gsr_frame_plan *plan, float *out_color, void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
-    if (!cam || !cam->bg || !image_ws || !out_color || num_rendered < 0 || (num_rendered > 0 && (!binning_ws || !geom_ws))) {
+    if (!cam || !cam->bg || !image_ws || !out_color || !plan || plan->num_rendered < 0 ||
+        (desc->P > 0 && !geom_ws) || (plan->num_rendered > 0 && !binning_ws)) {
         set_error("gsr_forward_render: NULL argument");
         return GSR_ERR_INVALID_ARGUMENT;
     }
+    if (plan->num_chunks < 1 || plan->num_chunks > GSR_MAX_CHUNKS) { set_error("bad plan (num_chunks %d)", plan->num_chunks); return GSR_ERR_INVALID_ARGUMENT; }
     hipStream_t s = (hipStream_t)stream;
     const bool dbg = desc->debug != 0;
     const FrameK f = make_frame(*desc);
-    GeomWS gw = carve_geom(geom_ws, f.P);
     ImageWS iw = carve_image(image_ws, f);
-    BinningWS bw = carve_binning(binning_ws, num_rendered);
-    int result = 0;
-    // the duplicate kernel takes the integer radius from the splat record, so this stage depends on the
-    // workspaces alone
-    if ((rc = launch_duplicate(f, gw, bw, num_rendered, dbg, s))) return rc;
-    if ((rc = launch_sort(f, bw, num_rendered, &result, dbg, s))) return rc;
-    if ((rc = launch_ranges(f, bw, result, iw, num_rendered, dbg, s))) return rc;
-    if ((rc = launch_render_fwd(f, *cam, gw, bw, iw, out_color, dbg, s))) return rc;
+    plan->chunks_run = 0; plan->instances_emitted = 0; plan->sort_result = 0;
+    if (f.P == 0 || plan->num_rendered == 0) {
+        // nothing to bin: one blend pass over empty ranges writes the background
+        GeomWS gw0 = carve_geom(geom_ws, f.P);
+        BinningWS bw0 = carve_binning(binning_ws, 0);
+        if (f.P == 0 || !geom_ws) gw0.ctrl = iw.ctrl_scratch;   // no geometry workspace at all
+        if ((rc = launch_binning_init(f, gw0, iw, dbg, s))) return rc;
+        if ((rc = launch_render_fwd(f, *cam, 0, true, gw0, bw0, iw, out_color, dbg, s))) return rc;
+        plan->chunks_run = 1;
+        return GSR_OK;
+    }
+    GeomWS gw = carve_geom(geom_ws, f.P);
+    BinningWS bw = carve_binning(binning_ws, plan->num_rendered);
+    if ((rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
+    int sort_result = 0;
+    for (int c = 0; c < plan->num_chunks; ++c) {
+        const bool last = c == plan->num_chunks - 1;
+        const int r0 = plan->chunk_rank_begin[c], r1 = plan->chunk_rank_begin[c + 1];
+        if ((rc = launch_chunk_binning(f, c, r0, r1, (uint64_t)plan->chunk_instances_max[c], gw, bw, iw, &sort_result, dbg, s)))
+            return rc;
+        if ((rc = launch_render_fwd(f, *cam, c, last, gw, bw, iw, out_color, dbg, s))) return rc;
+        plan->chunks_run = c + 1;
+        if (last) break;
+        if ((rc = launch_open_update(f, gw, iw, dbg, s))) return rc;
+        // one word back per chunk: stop as soon as no tile has an unsaturated pixel left
+        Ctrl h;
+        GSR_HIP_CHECK(hipMemcpyAsync(&h, gw.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+        GSR_HIP_CHECK(hipStreamSynchronize(s));
+        plan->instances_emitted = (int64_t)h.chunk_base[c + 1];
+        if (h.open_count == 0) break;
+        if (c + 1 == plan->num_chunks - 1) plan->instances_emitted = -1;   // the last chunk's count stays on the device
+    }
+    plan->sort_result = sort_result;
     return GSR_OK;
 }
 
 int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const void *geom_ws, void *binning_ws,
-                        const void *image_ws, int64_t num_rendered, const float *dL_dcolor, float *screen_grads, void *stream)
+                        const void *image_ws, const gsr_frame_plan *plan, const float *dL_dcolor, float *screen_grads,
+                        void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
-    if (!cam || !cam->bg || !dL_dcolor || (desc->P > 0 && (!screen_grads || !geom_ws)) || !image_ws ||
-        (num_rendered > 0 && !binning_ws)) {
+    if (!cam || !cam->bg || !dL_dcolor || !plan || (desc->P > 0 && (!screen_grads || !geom_ws)) || !image_ws ||
+        (plan->num_rendered > 0 && !binning_ws)) {
         set_error("gsr_backward_render: NULL argument");
         return GSR_ERR_INVALID_ARGUMENT;
     }
@@ -204,8 +240,10 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     if (f.P == 0) return GSR_OK;
     GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
     ImageWS iw = carve_image(const_cast<void *>(image_ws), f);
-    BinningWS bw = carve_binning(binning_ws, num_rendered);
-    if (num_rendered > 0 && (rc = launch_render_bwd(f, *cam, gw, bw, iw, dL_dcolor, dbg, s))) return rc;
+    BinningWS bw = carve_binning(binning_ws, plan->num_rendered);
+    if (plan->num_rendered > 0 &&
+        (rc = launch_render_bwd(f, *cam, plan->chunks_run, plan->sort_result, gw, bw, iw, dL_dcolor, dbg, s)))
+        return rc;
     if ((rc = launch_reduce_rows(f, gw, bw, screen_grads, dbg, s))) return rc;
     return GSR_OK;
 }
@@ -259,27 +297,27 @@ int gsr_profile_read(int max_entries, char (*names)[GSR_PROFILE_NAME_LEN], float
 }
 
 int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws, const void *image_ws,
-                        int64_t num_rendered, gsr_debug_views *v)
+                        const gsr_frame_plan *plan, gsr_debug_views *v)
 {
     int rc = validate(desc);
     if (rc) return rc;
-    if (!v) { set_error("NULL views"); return GSR_ERR_INVALID_ARGUMENT; }
+    if (!v || !plan) { set_error("NULL views / plan"); return GSR_ERR_INVALID_ARGUMENT; }
     memset(v, 0, sizeof *v);
     const FrameK f = make_frame(*desc);
     if (geom_ws) {
         GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
         v->splat_records = reinterpret_cast<const float *>(gw.records);
-        v->tiles_touched = gw.tiles_touched; v->point_offsets = gw.offsets; v->clamped = gw.clamped;
+        v->tiles_touched = gw.tiles_touched; v->depth_order = gw.order; v->point_offsets = gw.offs_full;
+        v->clamped = gw.clamped;
     }
     if (binning_ws) {
-        BinningWS bw = carve_binning(const_cast<void *>(binning_ws), num_rendered);
-        v->sorted_keys = nullptr;     // key buffers are scratch once the ranges are known
+        BinningWS bw = carve_binning(const_cast<void *>(binning_ws), plan->num_rendered);
         v->sorted_gaussian = bw.sorted_gid;
     }
     if (image_ws) {
         ImageWS iw = carve_image(const_cast<void *>(image_ws), f);
         v->ranges = reinterpret_cast<const uint32_t *>(iw.ranges);
-        v->final_T = iw.final_T; v->n_contrib = iw.n_contrib;
+        v->final_T = iw.T_state; v->n_contrib = iw.last_enc;
     }
     return GSR_OK;
 }

@@ -1,41 +1,30 @@
-// gsr_binning.hip — tile binning: prefix sum of tiles touched (K2), duplicate-with-keys (K3),
-// stable radix tile-sort restricted to the live key bits (K4), tile ranges (K5).  Spec: SURVEY A.7.
+// gsr_binning.hip — PROGRESSIVE tile binning (spec: SURVEY A.7; same per-tile order as a global stable
+// sort on (tile << 32 | depth bits), i.e. (tile, depth, Gaussian index)).
 //
-// Key = (tile_id << 32) | binary32 bits of the view-space depth; payload = instance slot (the index of
-// the instance in duplicate order = Gaussian-major).  Sorting slots instead of Gaussian ids lets the
-// backward write one private gradient row per instance and reduce them per Gaussian in a fixed
-// order — no float atomics, bitwise-reproducible gradients (MI355X float atomics run at ~1.3 TB/s
-// when well shaped and ~17x slower when scattered one dword per row: MI355X_MICROARCH "Global float
-// atomics").  Ties in (tile, depth) resolve by slot = ascending Gaussian index, as A.7 requires.
+// The reference duplicates every visible Gaussian into every tile of its rectangle and radix-sorts all
+// R = sum(tiles touched) 64-bit keys.  On MI355X that sort is pure HBM traffic (24 B x R x passes) and
+// most of it is wasted whenever tiles saturate: at the BASELINE cfg3 scene R = 43.8 M but every tile has
+// all 256 pixels below the 1e-4 transmittance cut-off after the nearest ~0.3 % of the Gaussians; only
+// 1.4 M of the 43.8 M instances can ever touch a pixel.  So:
+//
+//   1. sort the P Gaussians ONCE by depth (32-bit keys, invisible ones last)           [P-sized]
+//   2. inclusive scan of tiles touched in depth order; plan up to 8 depth chunks whose cumulative
+//      instance counts double (R/64, R/32, ... R), at least 256 k instances in the first      [P-sized]
+//   3. per chunk: count instances that fall into OPEN tiles (O(1) per Gaussian through a summed-area
+//      table of the open flags), scan, emit (tile id, slot) pairs in depth order, stable radix sort on the
+//      tile id only (2 passes of 8 bits), tile ranges, blend (gsr_render.hip), rebuild open flags + SAT.
+//      The host reads back ONE word per chunk (open tiles left) and stops when it is zero.
+//
+// A tile is closed only when every pixel has taken the A.8 cut-off, after which no further splat can
+// change any of its pixels (forward) or receive gradient from them (backward): pixels are identical.
+// Payload = slot (absolute emission index, Gaussian-major inside a chunk): the backward writes one
+// private gradient row per instance and reduces per Gaussian over a contiguous slot range in fixed
+// order - no float atomics, bitwise-reproducible gradients.
 #include "gsr_internal.h"
-
-#include <cstring>
-#include <string.h>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 namespace gsr {
 
-size_t scan_temp_bytes(int P)
-{
-    size_t bytes = 0;
-    if (P > 0)
-        (void)rocprim::inclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P,
-                                      rocprim::plus<uint32_t>());
-    return bytes;
-}
-
-size_t sort_temp_bytes(int64_t R)
-{
-    size_t bytes = 0;
-    if (R > 0) {
-        rocprim::double_buffer<uint64_t> k(nullptr, nullptr);
-        rocprim::double_buffer<uint32_t> v(nullptr, nullptr);
-        (void)rocprim::radix_sort_pairs(nullptr, bytes, k, v, (size_t)R, 0, 64);
-    }
-    return bytes;
-}
+constexpr uint32_t kMinFirstChunk = 262144;     // instances in the first depth chunk (at least)
 
 GeomWS carve_geom(void *base, int P)
 {
@@ -45,10 +34,18 @@ GeomWS carve_geom(void *base, int P)
     const size_t Pn = (size_t)(P > 0 ? P : 1);
     w.records = (float4 *)(b + o); o += align_up(Pn * 48);
     w.tiles_touched = (uint32_t *)(b + o); o += align_up(Pn * 4);
-    w.offsets = (uint32_t *)(b + o); o += align_up(Pn * 4);
     w.clamped = (uint8_t *)(b + o); o += align_up(Pn);
-    w.scan_temp_bytes = scan_temp_bytes(P);
-    w.scan_temp = b + o; o += align_up(w.scan_temp_bytes + 16);
+    for (int i = 0; i < 2; ++i) { w.sort_keys[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
+    for (int i = 0; i < 2; ++i) { w.sort_vals[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
+    w.order = w.sort_vals[0];                    // 4 passes of 8 bits: the result lands back in buffer 0
+    w.tiles_sorted = (uint32_t *)(b + o); o += align_up(Pn * 4);
+    w.offs_full = (uint32_t *)(b + o); o += align_up(Pn * 4);
+    w.cnt_open = (uint32_t *)(b + o); o += align_up(Pn * 4);
+    w.offs_open = (uint32_t *)(b + o); o += align_up(Pn * 4);
+    w.row_begin = (uint32_t *)(b + o); o += align_up(Pn * 4);
+    w.ctrl = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
+    w.scan_temp = b + o; o += scan_temp_bytes((int)Pn);
+    w.radix_temp = b + o; o += radix_temp_bytes();
     w.total = o;
     return w;
 }
@@ -59,9 +56,12 @@ ImageWS carve_image(void *base, const FrameK &f)
     size_t o = 0;
     char *b = (char *)base;
     const size_t N = (size_t)f.W * f.H, Tn = (size_t)f.Gx * f.Gy;
-    w.final_T = (float *)(b + o); o += align_up((N ? N : 1) * 4);
-    w.n_contrib = (int32_t *)(b + o); o += align_up((N ? N : 1) * 4);
-    w.ranges = (uint2 *)(b + o); o += align_up((Tn ? Tn : 1) * 8);
+    w.T_state = (float *)(b + o); o += align_up((N ? N : 1) * 4);
+    w.last_enc = (int32_t *)(b + o); o += align_up((N ? N : 1) * 4);
+    w.ranges = (uint2 *)(b + o); o += align_up((Tn ? Tn : 1) * 8 * GSR_MAX_CHUNKS);
+    w.open = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
+    w.sat = (uint32_t *)(b + o); o += align_up((size_t)(f.Gx + 1) * (f.Gy + 1) * 4);
+    w.ctrl_scratch = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
     w.total = o;
     return w;
 }
@@ -72,65 +72,230 @@ BinningWS carve_binning(void *base, int64_t R)
     size_t o = 0;
     char *b = (char *)base;
     const size_t Rn = (size_t)(R > 0 ? R : 1);
-    for (int i = 0; i < 2; ++i) { w.keys[i] = (uint64_t *)(b + o); o += align_up(Rn * 8); }
+    for (int i = 0; i < 2; ++i) { w.keys[i] = (uint32_t *)(b + o); o += align_up(Rn * 4); }
     for (int i = 0; i < 2; ++i) { w.vals[i] = (uint32_t *)(b + o); o += align_up(Rn * 4); }
     w.inst_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
     w.sorted_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
-    w.sorted_slot = (uint32_t *)(b + o); o += align_up(Rn * 4);
     w.grad_rows = (float *)(b + o); o += align_up(Rn * kRowFloats * 4);
-    w.sort_temp_bytes = sort_temp_bytes(R);
-    w.sort_temp = b + o; o += align_up(w.sort_temp_bytes + 16);
     w.total = o;
     return w;
 }
 
-int launch_scan(GeomWS &ws, int P, bool debug, hipStream_t s)
-{
-    if (P == 0) return GSR_OK;
-    size_t bytes = ws.scan_temp_bytes;
-    ProfileScope prof("scan", s);
-    GSR_HIP_CHECK(rocprim::inclusive_scan(ws.scan_temp, bytes, ws.tiles_touched, ws.offsets, (size_t)P,
-                                          rocprim::plus<uint32_t>(), s));
-    GSR_LAUNCH_CHECK("scan", debug, s);
-    return GSR_OK;
-}
-
 constexpr int kBinBlock = 256;
 
-// ---- K3: one thread per Gaussian walks its (slab-clipped) tile rectangle in row-major order.
-__global__ __launch_bounds__(kBinBlock) void k_duplicate(FrameK f, const float4 *__restrict__ records,
-                                                         const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ offsets,
-                                                         uint64_t *__restrict__ keys,
-                                                         uint32_t *__restrict__ vals, uint32_t *__restrict__ inst_gid)
+// ---- depth order: sort (depth bits, Gaussian) pairs written by the preprocess kernel, then gather the
+// tile counts into depth order and scan them.
+__global__ __launch_bounds__(kBinBlock) void k_gather_tiles(int P, const uint32_t *__restrict__ order,
+                                                            const uint32_t *__restrict__ tiles, uint32_t *__restrict__ tiles_sorted,
+                                                            uint32_t *__restrict__ cnt_open)
 {
-    const int i = blockIdx.x * kBinBlock + threadIdx.x;
-    if (i >= f.P) return;
-    const uint32_t cnt = tiles[i];
-    if (cnt == 0) return;
-    const float4 r0 = records[3 * (size_t)i];
-    const float4 r2 = records[3 * (size_t)i + 2];
-    const float depth = r2.y;
-    TileRect r = tile_rect(r0.x, r0.y, r2.z, f);
-    slab_clip(r, f);
-    uint32_t off = offsets[i] - cnt;
-    const uint64_t dbits = (uint64_t)__float_as_uint(depth);
-    for (int y = r.y0; y < r.y1; ++y)
-        for (int x = r.x0; x < r.x1; ++x) {
-            keys[off] = ((uint64_t)(uint32_t)(y * f.Gx + x) << 32) | dbits;
-            vals[off] = off;
-            inst_gid[off] = (uint32_t)i;
-            ++off;
-        }
+    const int r = blockIdx.x * kBinBlock + threadIdx.x;
+    if (r >= P) return;
+    tiles_sorted[r] = tiles[order[r]];
+    cnt_open[r] = 0;
 }
 
-int launch_duplicate(const FrameK &f, const GeomWS &gw, BinningWS &bw, int64_t R, bool debug, hipStream_t s)
+int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 {
-    if (f.P == 0 || R == 0) return GSR_OK;
-    ProfileScope prof("duplicate", s);
-    hipLaunchKernelGGL(k_duplicate, dim3((f.P + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, s, f, gw.records,
-                       gw.tiles_touched, gw.offsets, bw.keys[0], bw.vals[0], bw.inst_gid);
-    GSR_LAUNCH_CHECK("duplicate", debug, s);
+    if (f.P == 0) return GSR_OK;
+    int result = 0, rc;
+    if ((rc = launch_radix_sort<uint32_t>(ws.sort_keys, ws.sort_vals, nullptr, (uint32_t)f.P, (uint64_t)f.P, nullptr, 0, 32,
+                                          ws.radix_temp, &result, "depth_sort", debug, s)))
+        return rc;
+    if (result != 0) { set_error("internal: depth sort result buffer %d", result); return GSR_ERR_HIP; }
+    {
+        ProfileScope prof("gather_tiles", s);
+        hipLaunchKernelGGL(k_gather_tiles, dim3((f.P + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, s, f.P, ws.order,
+                           ws.tiles_touched, ws.tiles_sorted, ws.cnt_open);
+        GSR_LAUNCH_CHECK("gather_tiles", debug, s);
+    }
+    return launch_scan_inclusive(ws.tiles_sorted, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, "scan_tiles", debug, s);
+}
+
+// ---- chunk plan (one thread): V by binary search on the sorted keys, chunk boundaries by binary search on
+// the inclusive scan.  Cumulative targets double: first, 2 first, 4 first, ... with the last chunk taking
+// everything that is left.
+__global__ void k_chunk_plan(int P, const uint32_t *__restrict__ sorted_keys, const uint32_t *__restrict__ offs_full, Ctrl *ctrl)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int lo = 0, hi = P;                                   // V = first rank with key == 0xFFFFFFFF
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] != 0xFFFFFFFFu) lo = mid + 1; else hi = mid; }
+    const uint32_t V = (uint32_t)lo;
+    const uint32_t R = ctrl->R_total;
+    ctrl->V = V;
+    ctrl->open_count = 0;
+    uint32_t first = R / 64u;
+    if (first < kMinFirstChunk) first = kMinFirstChunk;
+    uint32_t nchunks = 0;
+    ctrl->bnd[0] = 0;
+    ctrl->chunk_base[0] = 0;
+    for (int c = 0; c < GSR_MAX_CHUNKS; ++c) {
+        ctrl->chunk_full[c] = 0; ctrl->chunk_R[c] = 0; ctrl->bnd[c + 1] = V; ctrl->chunk_base[c + 1] = 0;
+    }
+    uint32_t begin = 0;
+    for (int c = 0; c < GSR_MAX_CHUNKS && begin < V; ++c) {
+        uint32_t end = V;
+        const uint64_t target = (uint64_t)first << c;
+        if (c < GSR_MAX_CHUNKS - 1 && target < (uint64_t)R) {
+            int l = (int)begin, h = (int)V;             // first rank whose inclusive count exceeds the target
+            while (l < h) { const int mid = (l + h) >> 1; if ((uint64_t)offs_full[mid] <= target) l = mid + 1; else h = mid; }
+            end = (uint32_t)l;
+            if (end <= begin) end = begin + 1;
+            if (end > V) end = V;
+        }
+        ctrl->bnd[c + 1] = end;
+        ctrl->chunk_full[c] = offs_full[end - 1] - (begin ? offs_full[begin - 1] : 0u);
+        begin = end;
+        nchunks = (uint32_t)c + 1;
+    }
+    ctrl->num_chunks = nchunks;
+}
+
+int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
+{
+    ProfileScope prof("chunk_plan", s);
+    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(64), 0, s, f.P, ws.sort_keys[0], ws.offs_full, ws.ctrl);
+    GSR_LAUNCH_CHECK("chunk_plan", debug, s);
     return GSR_OK;
+}
+
+// ---- open flags + summed-area table.  One block; Tn is a few thousand to a few ten-thousand tiles.
+// sat[y][x] = number of open tiles in rows < y and columns < x   (dimensions (Gy+1) x (Gx+1)).
+__global__ __launch_bounds__(1024) void k_open_sat(FrameK f, int init, uint32_t *__restrict__ open, uint32_t *__restrict__ sat,
+                                                   Ctrl *ctrl)
+{
+    __shared__ uint32_t sh_count;
+    const int Gx = f.Gx, Gy = f.Gy, S = Gx + 1;
+    if (threadIdx.x == 0) sh_count = 0;
+    __syncthreads();
+    if (init)
+        for (int t = threadIdx.x; t < Gx * Gy; t += blockDim.x) {
+            const int ty = t / Gx;
+            open[t] = (ty >= f.ty0 && ty < f.ty1) ? 1u : 0u;
+        }
+    __syncthreads();
+    // row-wise prefix (one thread per tile row), then column-wise prefix (one thread per column)
+    for (int y = threadIdx.x; y <= Gy; y += blockDim.x) {
+        uint32_t run = 0;
+        sat[y * S] = 0;
+        for (int x = 0; x < Gx; ++x) {
+            if (y > 0) run += open[(y - 1) * Gx + x];
+            sat[y * S + x + 1] = run;
+        }
+        if (y > 0) atomicAdd(&sh_count, run);
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x <= Gx; x += blockDim.x) {
+        uint32_t run = 0;
+        for (int y = 0; y <= Gy; ++y) { run += sat[y * S + x]; sat[y * S + x] = run; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ctrl->open_count = sh_count;
+}
+
+int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
+{
+    const size_t Tn = (size_t)f.Gx * f.Gy;
+    GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, Tn * sizeof(uint2) * GSR_MAX_CHUNKS, s));
+    ProfileScope prof("open_sat", s);
+    hipLaunchKernelGGL(k_open_sat, dim3(1), dim3(1024), 0, s, f, 1, iw.open, iw.sat, gw.ctrl);
+    GSR_LAUNCH_CHECK("open_sat(init)", debug, s);
+    return GSR_OK;
+}
+
+int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
+{
+    ProfileScope prof("open_sat", s);
+    hipLaunchKernelGGL(k_open_sat, dim3(1), dim3(1024), 0, s, f, 0, iw.open, iw.sat, gw.ctrl);
+    GSR_LAUNCH_CHECK("open_sat", debug, s);
+    return GSR_OK;
+}
+
+// ---- per chunk: count instances into open tiles (SAT: O(1) per Gaussian)
+__global__ __launch_bounds__(kBinBlock) void k_count_open(FrameK f, int r0, int r1, const uint32_t *__restrict__ order,
+                                                          const float4 *__restrict__ records, const uint32_t *__restrict__ sat,
+                                                          uint32_t *__restrict__ cnt_open)
+{
+    const int r = r0 + blockIdx.x * kBinBlock + threadIdx.x;
+    if (r >= r1) return;
+    const uint32_t g = order[r];
+    const float4 a = records[3 * (size_t)g], c = records[3 * (size_t)g + 2];
+    TileRect t = tile_rect(a.x, a.y, c.z, f);
+    slab_clip(t, f);
+    const int S = f.Gx + 1;
+    uint32_t cnt = 0;
+    if (t.x1 > t.x0 && t.y1 > t.y0)
+        cnt = sat[t.y1 * S + t.x1] - sat[t.y0 * S + t.x1] - sat[t.y1 * S + t.x0] + sat[t.y0 * S + t.x0];
+    cnt_open[r] = cnt;
+}
+
+__global__ void k_chunk_finish(int c, Ctrl *ctrl)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctrl->chunk_base[c + 1] = ctrl->chunk_base[c] + ctrl->chunk_R[c];
+}
+
+// ---- emit (tile, slot) pairs of the chunk's Gaussians in depth order, open tiles only.  One WAVE walks one
+// Gaussian's rectangle cooperatively (ballot + popcount gives each open tile its ordinal), so a splat that
+// covers thousands of tiles does not serialise on one lane; 4 Gaussians per 256-thread block per step.
+__global__ __launch_bounds__(kBinBlock) void k_emit(FrameK f, int c, int r0, int r1, const uint32_t *__restrict__ order,
+                                                    const float4 *__restrict__ records, const uint32_t *__restrict__ open,
+                                                    const uint32_t *__restrict__ cnt_open, const uint32_t *__restrict__ offs_open,
+                                                    const Ctrl *__restrict__ ctrl, uint32_t *__restrict__ keys,
+                                                    uint32_t *__restrict__ vals, uint32_t *__restrict__ inst_gid,
+                                                    uint32_t *__restrict__ row_begin)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * kBinBlock + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * kBinBlock) >> 6;
+    const uint32_t base = ctrl->chunk_base[c];
+    for (int r = r0 + wave; r < r1; r += n_waves) {
+        const uint32_t cnt = cnt_open[r];
+        const uint32_t first = base + offs_open[r] - cnt;
+        if (lane == 0) row_begin[r] = first;
+        if (cnt == 0) continue;
+        const uint32_t g = order[r];
+        const float4 a = records[3 * (size_t)g], cc = records[3 * (size_t)g + 2];
+        TileRect t = tile_rect(a.x, a.y, cc.z, f);
+        slab_clip(t, f);
+        const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0);
+        uint32_t emitted = 0;
+        for (int i0 = 0; i0 < total; i0 += kWave) {
+            const int i = i0 + lane;
+            uint32_t tile = 0;
+            bool is_open = false;
+            if (i < total) {
+                tile = (uint32_t)((t.y0 + i / w) * f.Gx + t.x0 + i % w);
+                is_open = open[tile] != 0;
+            }
+            const unsigned long long m = __ballot(is_open);
+            if (is_open) {
+                const uint32_t slot = first + emitted + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                keys[slot] = tile;
+                vals[slot] = slot;
+                inst_gid[slot] = g;
+            }
+            emitted += (uint32_t)__popcll(m);
+        }
+    }
+}
+
+// ---- ranges of the chunk's sorted list (grid-stride, element count on the device)
+__global__ __launch_bounds__(kBinBlock) void k_ranges(int c, const Ctrl *__restrict__ ctrl, const uint32_t *__restrict__ keys,
+                                                      const uint32_t *__restrict__ slots, const uint32_t *__restrict__ inst_gid,
+                                                      uint2 *__restrict__ ranges, uint32_t *__restrict__ sorted_gid)
+{
+    const uint32_t n = ctrl->chunk_R[c], base = ctrl->chunk_base[c];
+    for (uint32_t i = blockIdx.x * kBinBlock + threadIdx.x; i < n; i += gridDim.x * kBinBlock) {
+        const uint32_t a = base + i;
+        const uint32_t tile = keys[a];
+        if (i == 0) ranges[tile].x = a;
+        else {
+            const uint32_t prev = keys[a - 1];
+            if (prev != tile) { ranges[prev].y = a; ranges[tile].x = a; }
+        }
+        if (i == n - 1) ranges[tile].y = a + 1;
+        sorted_gid[a] = inst_gid[slots[a]];
+    }
 }
 
 static int msb_plus1(uint32_t n)
@@ -140,52 +305,44 @@ static int msb_plus1(uint32_t n)
     return b;
 }
 
-// ---- K4: stable LSD radix sort over the live bits only: 32 depth bits + ceil(log2(Tn)) tile bits.
-int launch_sort(const FrameK &f, BinningWS &bw, int64_t R, int *result_buffer, bool debug, hipStream_t s)
+int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, GeomWS &gw, BinningWS &bw, ImageWS &iw,
+                         int *sort_result, bool debug, hipStream_t s)
 {
-    *result_buffer = 0;
-    if (R == 0) return GSR_OK;
-    const int end_bit = 32 + msb_plus1((uint32_t)(f.Gx * f.Gy));
-    rocprim::double_buffer<uint64_t> k(bw.keys[0], bw.keys[1]);
-    rocprim::double_buffer<uint32_t> v(bw.vals[0], bw.vals[1]);
-    size_t bytes = bw.sort_temp_bytes;
-    ProfileScope prof("radix_sort", s);
-    GSR_HIP_CHECK(rocprim::radix_sort_pairs(bw.sort_temp, bytes, k, v, (size_t)R, 0, (unsigned)end_bit, s));
-    *result_buffer = (k.current() == bw.keys[0]) ? 0 : 1;
-    GSR_LAUNCH_CHECK("radix_sort", debug, s);
-    return GSR_OK;
-}
-
-// ---- K5: tile boundaries in the sorted keys -> ranges; also materialises sorted position -> Gaussian.
-__global__ __launch_bounds__(kBinBlock) void k_ranges(int64_t R, const uint64_t *__restrict__ keys,
-                                                      const uint32_t *__restrict__ slots, const uint32_t *__restrict__ inst_gid,
-                                                      uint2 *__restrict__ ranges, uint32_t *__restrict__ sorted_gid,
-                                                      uint32_t *__restrict__ sorted_slot)
-{
-    const int64_t i = (int64_t)blockIdx.x * kBinBlock + threadIdx.x;
-    if (i >= R) return;
-    const uint32_t tile = (uint32_t)(keys[i] >> 32);
-    if (i == 0) ranges[tile].x = 0;
-    else {
-        const uint32_t prev = (uint32_t)(keys[i - 1] >> 32);
-        if (prev != tile) { ranges[prev].y = (uint32_t)i; ranges[tile].x = (uint32_t)i; }
-    }
-    if (i == R - 1) ranges[tile].y = (uint32_t)R;
-    const uint32_t slot = slots[i];
-    sorted_slot[i] = slot;
-    sorted_gid[i] = inst_gid[slot];
-}
-
-int launch_ranges(const FrameK &f, BinningWS &bw, int result_buffer, ImageWS &iw, int64_t R, bool debug, hipStream_t s)
-{
+    int rc;
+    const int n = r1 - r0;
+    if (n <= 0) return GSR_OK;
     const size_t Tn = (size_t)f.Gx * f.Gy;
-    GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, Tn * sizeof(uint2), s));
-    if (R == 0) return GSR_OK;
-    ProfileScope prof("ranges", s);
-    hipLaunchKernelGGL(k_ranges, dim3((unsigned)((R + kBinBlock - 1) / kBinBlock)), dim3(kBinBlock), 0, s, R,
-                       bw.keys[result_buffer], bw.vals[result_buffer], bw.inst_gid, iw.ranges, bw.sorted_gid,
-                       bw.sorted_slot);
-    GSR_LAUNCH_CHECK("ranges", debug, s);
+    {
+        ProfileScope prof("count_open", s);
+        hipLaunchKernelGGL(k_count_open, dim3((n + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, s, f, r0, r1, gw.order,
+                           gw.records, iw.sat, gw.cnt_open);
+        GSR_LAUNCH_CHECK("count_open", debug, s);
+    }
+    if ((rc = launch_scan_inclusive(gw.cnt_open + r0, gw.offs_open + r0, n, gw.scan_temp, &gw.ctrl->chunk_R[c], "scan_open",
+                                    debug, s)))
+        return rc;
+    {
+        ProfileScope prof("emit", s);
+        hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(64), 0, s, c, gw.ctrl);
+        int blocks = (n + 3) / 4;                     // one wave per Gaussian per step
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records, iw.open, gw.cnt_open,
+                           gw.offs_open, gw.ctrl, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);
+        GSR_LAUNCH_CHECK("emit", debug, s);
+    }
+    const int tile_bits = msb_plus1((uint32_t)(Tn ? Tn - 1 : 0));
+    if ((rc = launch_radix_sort<uint32_t>(bw.keys, bw.vals, &gw.ctrl->chunk_R[c], 0, n_max, &gw.ctrl->chunk_base[c], 0,
+                                          tile_bits > 0 ? tile_bits : 1, gw.radix_temp, sort_result, "tile_sort", debug, s)))
+        return rc;
+    {
+        ProfileScope prof("ranges", s);
+        uint64_t blocks = (n_max + kBinBlock - 1) / kBinBlock;
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k_ranges, dim3((unsigned)blocks), dim3(kBinBlock), 0, s, c, gw.ctrl, bw.keys[*sort_result],
+                           bw.vals[*sort_result], bw.inst_gid, iw.ranges + (size_t)c * Tn, bw.sorted_gid);
+        GSR_LAUNCH_CHECK("ranges", debug, s);
+    }
     return GSR_OK;
 }
 

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
                                                            const float *__restrict__ opac, const float *__restrict__ shs,
                                                            const float *__restrict__ colpre, float4 *__restrict__ records,
                                                            uint32_t *__restrict__ tiles, uint8_t *__restrict__ clamped,
-                                                           int32_t *__restrict__ radii)
+                                                           int32_t *__restrict__ radii, uint32_t *__restrict__ sort_keys,
+                                                           uint32_t *__restrict__ sort_vals)
 {
     const int i = blockIdx.x * kGeomBlock + threadIdx.x;
     if (i >= f.P) return;
@@ -46,6 +47,9 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
     records[3 * (size_t)i + 0] = make_float4(o.s.x, o.s.y, o.s.cA, o.s.cB);
     records[3 * (size_t)i + 1] = make_float4(o.s.cC, o.s.op, o.s.r, o.s.g);
     records[3 * (size_t)i + 2] = make_float4(o.s.b, o.s.depth, o.s.radius, 0.f);
+    // depth-sort key: binary32 pattern of the (positive) view depth; invisible Gaussians sort last
+    sort_keys[i] = (o.radius > 0 && o.tiles > 0) ? __float_as_uint(o.s.depth) : 0xFFFFFFFFu;
+    sort_vals[i] = (uint32_t)i;
 }
 
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
@@ -57,7 +61,8 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 #define GSR_PRE(DEG)                                                                                              \
     hipLaunchKernelGGL(k_preprocess<DEG>, dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
                        cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs,         \
-                       g.colors_precomp, ws.records, ws.tiles_touched, ws.clamped, radii)
+                       g.colors_precomp, ws.records, ws.tiles_touched, ws.clamped, radii, ws.sort_keys[0],  \
+                       ws.sort_vals[0])
     switch (g.shs ? f.D : 0) {
         case 0: GSR_PRE(0); break;
         case 1: GSR_PRE(1); break;

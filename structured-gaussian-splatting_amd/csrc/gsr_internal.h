@@ -67,48 +67,76 @@ inline FrameK make_frame(const gsr_frame_desc &d)
 }
 
 // ---- workspace carving (all sub-arrays 256-B aligned; the caller's base is torch-allocated, 512-B aligned)
+struct Ctrl {                   // small device-side control block of one frame
+    uint32_t R_total, V, num_chunks, open_count;
+    uint32_t bnd[GSR_MAX_CHUNKS + 1];          // depth-rank boundaries of the chunks
+    uint32_t chunk_full[GSR_MAX_CHUNKS];       // instances of the chunk if every tile were open
+    uint32_t chunk_R[GSR_MAX_CHUNKS];          // instances actually emitted
+    uint32_t chunk_base[GSR_MAX_CHUNKS + 1];   // first absolute instance index of the chunk
+};
 struct GeomWS {                 // O(P): the reference's geomBuffer
-    float4 *records;            // [P,3]  Splat records
-    uint32_t *tiles_touched;    // [P]
-    uint32_t *offsets;          // [P]    inclusive scan of tiles_touched
-    uint8_t *clamped;           // [P]
-    void *scan_temp; size_t scan_temp_bytes;
+    float4 *records;            // [P,3]  Splat records, by Gaussian
+    uint32_t *tiles_touched;    // [P]    by Gaussian
+    uint8_t *clamped;           // [P]    by Gaussian
+    uint32_t *sort_keys[2];     // [P] x2 depth bits (0xFFFFFFFF = invisible)
+    uint32_t *sort_vals[2];     // [P] x2 Gaussian index; after the sort: depth rank -> Gaussian
+    uint32_t *order;            // alias of the sorted sort_vals buffer
+    uint32_t *tiles_sorted;     // [P]    tiles touched, in depth order
+    uint32_t *offs_full;        // [P]    inclusive scan of tiles_sorted
+    uint32_t *cnt_open;         // [P]    by rank: instances emitted for this Gaussian
+    uint32_t *offs_open;        // [P]    by rank: inclusive scan of cnt_open inside its chunk
+    uint32_t *row_begin;        // [P]    by rank: absolute index of the Gaussian's first instance
+    Ctrl *ctrl;
+    void *scan_temp;
+    void *radix_temp;
     size_t total;
 };
 struct ImageWS {                // O(N + Tn): the reference's imgBuffer
-    float *final_T;             // [N]
-    int32_t *n_contrib;         // [N]
-    uint2 *ranges;              // [Tn]
+    float *T_state;             // [N]  running / final transmittance; negative = pixel hit the cut-off
+    int32_t *last_enc;          // [N]  (chunk + 1) << 26 | contributor position in that chunk's range
+    uint2 *ranges;              // [GSR_MAX_CHUNKS][Tn]
+    uint32_t *open;             // [Tn] 1 = tile still has an unsaturated pixel (0 outside the slab)
+    uint32_t *sat;              // [(Gy+1)*(Gx+1)] summed-area table of `open`
+    Ctrl *ctrl_scratch;         // stand-in control block for frames without a geometry workspace (P == 0)
     size_t total;
 };
 struct BinningWS {              // O(R): the reference's binningBuffer
-    uint64_t *keys[2];          // [R] x2 (radix double buffer)
-    uint32_t *vals[2];          // [R] x2   payload = instance slot (index in duplicate order)
+    uint32_t *keys[2];          // [R] x2 tile id (radix double buffer)
+    uint32_t *vals[2];          // [R] x2 payload = instance slot (absolute index in emission order)
     uint32_t *inst_gid;         // [R] slot -> Gaussian
     uint32_t *sorted_gid;       // [R] sorted position -> Gaussian
-    uint32_t *sorted_slot;      // [R] sorted position -> slot (the sorted payload, kept for the backward)
     float *grad_rows;           // [R, kRowFloats] per-instance screen-space gradient rows (backward)
-    void *sort_temp; size_t sort_temp_bytes;
     size_t total;
 };
+constexpr int kLastShift = 26;  // last_enc = (chunk + 1) << kLastShift | position
 
-size_t scan_temp_bytes(int P);
-size_t sort_temp_bytes(int64_t R);
+size_t scan_temp_bytes(int n);
+size_t radix_temp_bytes();
 GeomWS carve_geom(void *base, int P);
 ImageWS carve_image(void *base, const FrameK &f);
 BinningWS carve_binning(void *base, int64_t R);
 
+// ---- primitives (gsr_sort.hip)
+int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const char *name,
+                          bool debug, hipStream_t s);
+template <typename K>
+int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
+                      const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,
+                      bool debug, hipStream_t s);
+
 // ---- kernel launchers (each returns a gsr_status)
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
                       bool debug, hipStream_t s);
-int launch_scan(GeomWS &ws, int P, bool debug, hipStream_t s);
-int launch_duplicate(const FrameK &f, const GeomWS &gw, BinningWS &bw, int64_t R, bool debug, hipStream_t s);
-int launch_sort(const FrameK &f, BinningWS &bw, int64_t R, int *result_buffer, bool debug, hipStream_t s);
-int launch_ranges(const FrameK &f, BinningWS &bw, int result_buffer, ImageWS &iw, int64_t R, bool debug, hipStream_t s);
-int launch_render_fwd(const FrameK &f, const gsr_camera &cam, const GeomWS &gw, const BinningWS &bw, ImageWS &iw,
-                      float *out_color, bool debug, hipStream_t s);
-int launch_render_bwd(const FrameK &f, const gsr_camera &cam, const GeomWS &gw, BinningWS &bw, const ImageWS &iw,
-                      const float *dL_dcolor, bool debug, hipStream_t s);
+int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
+int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
+int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
+int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, GeomWS &gw, BinningWS &bw, ImageWS &iw,
+                         int *sort_result, bool debug, hipStream_t s);
+int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
+int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
+                      ImageWS &iw, float *out_color, bool debug, hipStream_t s);
+int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, int sort_result, const GeomWS &gw, BinningWS &bw,
+                      const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s);
 int launch_reduce_rows(const FrameK &f, const GeomWS &gw, const BinningWS &bw, float *screen_grads, bool debug,
                        hipStream_t s);
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,

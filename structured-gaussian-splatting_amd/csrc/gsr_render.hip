@@ -61,32 +61,52 @@ __device__ __forceinline__ float bcast_lane63(float v)
 constexpr int kStrips = 4;
 
 // ------------------------------------------------------------------------------------------- K6
-__global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, const uint2 *__restrict__ ranges,
+// One launch per depth chunk.  A tile's wave resumes the pixels' state (T, colour, last contributor) where
+// the previous chunk left it, blends the chunk's range, and closes the tile once all 256 pixels have
+// taken the cut-off.  State lives in the image workspace: T_state (negative = done), last_enc, and the
+// un-finalised colour in out_color itself; the background term is added exactly once, when the tile
+// closes or after the last chunk.
+__global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int c, int finalize_all,
+                                                      const uint2 *__restrict__ ranges_c, uint32_t *__restrict__ open,
                                                       const uint32_t *__restrict__ sorted_gid,
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
-                                                      float *__restrict__ out_color, float *__restrict__ final_T,
-                                                      int32_t *__restrict__ n_contrib)
+                                                      float *__restrict__ out_color, float *__restrict__ T_state,
+                                                      int32_t *__restrict__ last_enc)
 {
     __shared__ float4 sh_rec[kWave * 3];
     const int t = xcd_remap(blockIdx.x, n_tiles);
     const int tx = t % f.Gx, ty = f.ty0 + t / f.Gx;
-    const uint2 rng = ranges[ty * f.Gx + tx];
+    const int tile = ty * f.Gx + tx;
+    if (open[tile] == 0u) return;                       // closed by an earlier chunk: pixels are final
+    const uint2 rng = ranges_c[tile];
     const int lane = threadIdx.x;
     const int px = tx * GSR_TILE + (lane & 15);
     const int py0 = ty * GSR_TILE + (lane >> 4);
     const float fx = (float)px;
+    const size_t N = (size_t)f.W * f.H;
 
     float fy[kStrips], T[kStrips], Cr[kStrips], Cg[kStrips], Cb[kStrips];
     int last[kStrips];
     bool done[kStrips];
 #pragma unroll
     for (int k = 0; k < kStrips; ++k) {
-        fy[k] = (float)(py0 + 4 * k);
+        const int py = py0 + 4 * k;
+        fy[k] = (float)py;
+        const bool inside = px < f.W && py < f.H;
         T[k] = 1.f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = 0;
-        done[k] = !(px < f.W && (py0 + 4 * k) < f.H);
+        done[k] = !inside;
+        if (c > 0 && inside) {
+            const size_t pix = (size_t)py * f.W + px;
+            const float ts = T_state[pix];
+            T[k] = fabsf(ts);
+            done[k] = ts < 0.f;
+            Cr[k] = out_color[pix]; Cg[k] = out_color[N + pix]; Cb[k] = out_color[2 * N + pix];
+            last[k] = last_enc[pix];
+        }
     }
 
     const int n_total = (int)(rng.y - rng.x);
+    const int enc_base = (c + 1) << kLastShift;
     for (int base = 0; base < n_total; base += kWave) {
         const bool all_done = done[0] && done[1] && done[2] && done[3];
         if (__ballot(!all_done) == 0ull) break;
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, con
             const float cb = sh_rec[3 * j + 2].x;
             const float dx = a.x - fx;
             const float axx = a.z * dx * dx, bx = a.w * dx;
-            const int contributor = base + j + 1;
+            const int contributor = enc_base | (base + j + 1);
 #pragma unroll
             for (int k = 0; k < kStrips; ++k) {
                 const float dy = a.y - fy[k];
@@ -123,8 +143,10 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, con
             }
         }
     }
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    const size_t N = (size_t)f.W * f.H;
+    const bool all_done = done[0] && done[1] && done[2] && done[3];
+    const bool closing = __ballot(!all_done) == 0ull;
+    const bool finalize = closing || finalize_all != 0;
+    const float bg0 = finalize ? bg[0] : 0.f, bg1 = finalize ? bg[1] : 0.f, bg2 = finalize ? bg[2] : 0.f;
 #pragma unroll
     for (int k = 0; k < kStrips; ++k) {
         const int py = py0 + 4 * k;
@@ -133,38 +155,43 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, con
             out_color[pix] = Cr[k] + T[k] * bg0;
             out_color[N + pix] = Cg[k] + T[k] * bg1;
             out_color[2 * N + pix] = Cb[k] + T[k] * bg2;
-            final_T[pix] = T[k];
-            n_contrib[pix] = last[k];
+            T_state[pix] = done[k] ? -T[k] : T[k];
+            last_enc[pix] = last[k];
         }
     }
+    if (lane == 0) open[tile] = closing ? 0u : 1u;
 }
 
-int launch_render_fwd(const FrameK &f, const gsr_camera &cam, const GeomWS &gw, const BinningWS &bw, ImageWS &iw,
-                      float *out_color, bool debug, hipStream_t s)
+int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
+                      ImageWS &iw, float *out_color, bool debug, hipStream_t s)
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0) return GSR_OK;
     ProfileScope prof("render_fwd", s);
-    hipLaunchKernelGGL(k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, iw.ranges, bw.sorted_gid, gw.records,
-                       cam.bg, out_color, iw.final_T, iw.n_contrib);
+    const size_t Tn = (size_t)f.Gx * f.Gy;
+    hipLaunchKernelGGL(k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, c, last_chunk ? 1 : 0,
+                       iw.ranges + (size_t)c * Tn, iw.open, bw.sorted_gid, gw.records, cam.bg, out_color, iw.T_state,
+                       iw.last_enc);
     GSR_LAUNCH_CHECK("render_fwd", debug, s);
     return GSR_OK;
 }
 
 // ------------------------------------------------------------------------------------------- K7
-__global__ __launch_bounds__(kWave) void k_render_bwd(FrameK f, int n_tiles, const uint2 *__restrict__ ranges,
+// One launch for the whole frame: a tile's wave walks its chunks last to first, each chunk's range back to
+// front.  A pixel takes part in chunk c up to its own last contributor (all of the range for chunks before
+// the one that holds it, nothing after).
+__global__ __launch_bounds__(kWave) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
                                                       const uint32_t *__restrict__ sorted_gid,
                                                       const uint32_t *__restrict__ sorted_slot,
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
-                                                      const float *__restrict__ final_T, const int32_t *__restrict__ n_contrib,
+                                                      const float *__restrict__ T_state, const int32_t *__restrict__ last_enc,
                                                       const float *__restrict__ dL_dpix, float4 *__restrict__ grad_rows)
 {
     __shared__ float4 sh_rec[kWave * 3];
     const int t = xcd_remap(blockIdx.x, n_tiles);
     const int tx = t % f.Gx, ty = f.ty0 + t / f.Gx;
-    const uint2 rng = ranges[ty * f.Gx + tx];
-    const int n_total = (int)(rng.y - rng.x);
-    if (n_total == 0) return;
+    const int tile = ty * f.Gx + tx;
+    const size_t Tn = (size_t)f.Gx * f.Gy;
     const int lane = threadIdx.x;
     const int px = tx * GSR_TILE + (lane & 15);
     const int py0 = ty * GSR_TILE + (lane >> 4);
@@ -174,136 +201,153 @@ __global__ __launch_bounds__(kWave) void k_render_bwd(FrameK f, int n_tiles, con
 
     float fy[kStrips], T[kStrips], bgterm[kStrips], dpr[kStrips], dpg[kStrips], dpb[kStrips];
     float ar[kStrips], ag[kStrips], ab[kStrips], lalpha[kStrips], lr[kStrips], lg[kStrips], lb[kStrips];
-    int ncon[kStrips];
-    int max_contrib = 0;
+    int c_last[kStrips], n_last[kStrips];
 #pragma unroll
     for (int k = 0; k < kStrips; ++k) {
         const int py = py0 + 4 * k;
         fy[k] = (float)py;
         const bool inside = px < f.W && py < f.H;
         const size_t pix = inside ? (size_t)py * f.W + px : 0;
-        T[k] = inside ? final_T[pix] : 0.f;
-        ncon[k] = inside ? n_contrib[pix] : 0;
+        T[k] = inside ? fabsf(T_state[pix]) : 0.f;
+        const int enc = inside ? last_enc[pix] : 0;
+        c_last[k] = (enc >> kLastShift) - 1;                              // -1: no contributor at all
+        n_last[k] = enc & ((1 << kLastShift) - 1);
         dpr[k] = inside ? dL_dpix[pix] : 0.f;
         dpg[k] = inside ? dL_dpix[N + pix] : 0.f;
         dpb[k] = inside ? dL_dpix[2 * N + pix] : 0.f;
         bgterm[k] = -T[k] * (bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k]);   // -T_final * <bg, dL/dpix>
         ar[k] = ag[k] = ab[k] = 0.f; lalpha[k] = 0.f; lr[k] = lg[k] = lb[k] = 0.f;
-        max_contrib = max(max_contrib, ncon[k]);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off));
-
     const float half_w = 0.5f * (float)f.W, half_h = 0.5f * (float)f.H;
-    const int n_batches = (n_total + kWave - 1) / kWave;
-    for (int bi = n_batches - 1; bi >= 0; --bi) {
-        const int base = bi * kWave;
-        const int n = min(kWave, n_total - base);
-        uint32_t slot = 0;
-        if (lane < n) slot = sorted_slot[rng.x + base + lane];
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, o4 = 0.f, o5 = 0.f, o6 = 0.f, o7 = 0.f, o8 = 0.f;
-        if (base < max_contrib) {
-            __syncthreads();
-            if (lane < n) {
-                const uint32_t gid = sorted_gid[rng.x + base + lane];
-                const float4 *r = records + 3 * (size_t)gid;
-                sh_rec[3 * lane + 0] = r[0];
-                sh_rec[3 * lane + 1] = r[1];
-                sh_rec[3 * lane + 2] = r[2];
-            }
-            __syncthreads();
-            for (int j = n - 1; j >= 0; --j) {
-                const int pos = base + j;                 // contributor index of this splat is pos + 1
-                if (pos >= max_contrib) continue;         // wave-uniform
-                const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
-                const float cb = sh_rec[3 * j + 2].x;
-                const float dx = a.x - fx;
-                const float axx = a.z * dx * dx, bx = a.w * dx;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
-                bool any_valid = false;
+
+    for (int c = chunks_run - 1; c >= 0; --c) {
+        const uint2 rng = ranges[(size_t)c * Tn + tile];
+        const int n_total = (int)(rng.y - rng.x);
+        if (n_total == 0) continue;
+        int limit[kStrips];
+        int max_contrib = 0;
 #pragma unroll
-                for (int k = 0; k < kStrips; ++k) {
-                    const float dy = a.y - fy[k];
-                    const float power = -0.5f * (axx + b.x * dy * dy) - bx * dy;
-                    const float G = fast_exp(fminf(power, 0.f));         // power > 0 lanes are rejected; keep G finite
-                    const float alpha = fminf((float)GSR_ALPHA_MAX, b.y * G);
-                    const bool valid = (pos < ncon[k]) && !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
-                    any_valid = any_valid || valid;
-                    const float inv1ma = fast_rcp(1.f - alpha);
-                    const float Tn = T[k] * inv1ma;                       // T before this splat
-                    const float w = alpha * Tn;                           // d colour / d rgb
-                    const float nar = lalpha[k] * lr[k] + (1.f - lalpha[k]) * ar[k];
-                    const float nag = lalpha[k] * lg[k] + (1.f - lalpha[k]) * ag[k];
-                    const float nab = lalpha[k] * lb[k] + (1.f - lalpha[k]) * ab[k];
-                    float dL_dalpha = (b.z - nar) * dpr[k] + (b.w - nag) * dpg[k] + (cb - nab) * dpb[k];
-                    dL_dalpha = dL_dalpha * Tn + bgterm[k] * inv1ma;
-                    const float dL_dG = b.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                    const float dG_ddely = -gdy * b.x - gdx * a.w;
-                    const float v = valid ? 1.f : 0.f;
-                    const float vG = v * dL_dG;
-                    s0 += vG * dG_ddelx;
-                    s1 += vG * dG_ddely;
-                    s2 += vG * gdx * dx;
-                    s3 += vG * gdx * dy;
-                    s4 += vG * gdy * dy;
-                    s5 += v * G * dL_dalpha;
-                    const float vw = v * w;
-                    s6 += vw * dpr[k]; s7 += vw * dpg[k]; s8 += vw * dpb[k];
-                    T[k] = valid ? Tn : T[k];
-                    ar[k] = valid ? nar : ar[k]; ag[k] = valid ? nag : ag[k]; ab[k] = valid ? nab : ab[k];
-                    lr[k] = valid ? b.z : lr[k]; lg[k] = valid ? b.w : lg[k]; lb[k] = valid ? cb : lb[k];
-                    lalpha[k] = valid ? alpha : lalpha[k];
-                }
-                if (__ballot(any_valid) == 0ull) continue;               // nobody accepted this splat: row stays 0
-                s0 = bcast_lane63(wave_sum_to_lane63(s0)) * half_w;
-                s1 = bcast_lane63(wave_sum_to_lane63(s1)) * half_h;
-                s2 = bcast_lane63(wave_sum_to_lane63(s2)) * -0.5f;
-                s3 = bcast_lane63(wave_sum_to_lane63(s3)) * -0.5f;
-                s4 = bcast_lane63(wave_sum_to_lane63(s4)) * -0.5f;
-                s5 = bcast_lane63(wave_sum_to_lane63(s5));
-                s6 = bcast_lane63(wave_sum_to_lane63(s6));
-                s7 = bcast_lane63(wave_sum_to_lane63(s7));
-                s8 = bcast_lane63(wave_sum_to_lane63(s8));
-                if (lane == j) { o0 = s0; o1 = s1; o2 = s2; o3 = s3; o4 = s4; o5 = s5; o6 = s6; o7 = s7; o8 = s8; }
-            }
+        for (int k = 0; k < kStrips; ++k) {
+            limit[k] = c < c_last[k] ? n_total : (c == c_last[k] ? n_last[k] : 0);
+            max_contrib = max(max_contrib, limit[k]);
         }
-        if (lane < n) {
-            float4 *row = grad_rows + 3 * (size_t)slot;
-            row[0] = make_float4(o0, o1, o2, o3);
-            row[1] = make_float4(o4, o5, o6, o7);
-            row[2] = make_float4(o8, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off));
+
+        const int n_batches = (n_total + kWave - 1) / kWave;
+        for (int bi = n_batches - 1; bi >= 0; --bi) {
+            const int base = bi * kWave;
+            const int n = min(kWave, n_total - base);
+            uint32_t slot = 0;
+            if (lane < n) slot = sorted_slot[rng.x + base + lane];
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, o4 = 0.f, o5 = 0.f, o6 = 0.f, o7 = 0.f, o8 = 0.f;
+            if (base < max_contrib) {
+                __syncthreads();
+                if (lane < n) {
+                    const uint32_t gid = sorted_gid[rng.x + base + lane];
+                    const float4 *r = records + 3 * (size_t)gid;
+                    sh_rec[3 * lane + 0] = r[0];
+                    sh_rec[3 * lane + 1] = r[1];
+                    sh_rec[3 * lane + 2] = r[2];
+                }
+                __syncthreads();
+                for (int j = n - 1; j >= 0; --j) {
+                    const int pos = base + j;                 // contributor index of this splat is pos + 1
+                    if (pos >= max_contrib) continue;         // wave-uniform
+                    const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
+                    const float cb = sh_rec[3 * j + 2].x;
+                    const float dx = a.x - fx;
+                    const float axx = a.z * dx * dx, bx = a.w * dx;
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
+                    bool any_valid = false;
+#pragma unroll
+                    for (int k = 0; k < kStrips; ++k) {
+                        const float dy = a.y - fy[k];
+                        const float power = -0.5f * (axx + b.x * dy * dy) - bx * dy;
+                        const float G = fast_exp(fminf(power, 0.f));         // power > 0 lanes are rejected; keep G finite
+                        const float alpha = fminf((float)GSR_ALPHA_MAX, b.y * G);
+                        const bool valid = (pos < limit[k]) && !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
+                        any_valid = any_valid || valid;
+                        const float inv1ma = fast_rcp(1.f - alpha);
+                        const float Tn_ = T[k] * inv1ma;                      // T before this splat
+                        const float w = alpha * Tn_;                          // d colour / d rgb
+                        const float nar = lalpha[k] * lr[k] + (1.f - lalpha[k]) * ar[k];
+                        const float nag = lalpha[k] * lg[k] + (1.f - lalpha[k]) * ag[k];
+                        const float nab = lalpha[k] * lb[k] + (1.f - lalpha[k]) * ab[k];
+                        float dL_dalpha = (b.z - nar) * dpr[k] + (b.w - nag) * dpg[k] + (cb - nab) * dpb[k];
+                        dL_dalpha = dL_dalpha * Tn_ + bgterm[k] * inv1ma;
+                        const float dL_dG = b.y * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                        const float dG_ddely = -gdy * b.x - gdx * a.w;
+                        const float v = valid ? 1.f : 0.f;
+                        const float vG = v * dL_dG;
+                        s0 += vG * dG_ddelx;
+                        s1 += vG * dG_ddely;
+                        s2 += vG * gdx * dx;
+                        s3 += vG * gdx * dy;
+                        s4 += vG * gdy * dy;
+                        s5 += v * G * dL_dalpha;
+                        const float vw = v * w;
+                        s6 += vw * dpr[k]; s7 += vw * dpg[k]; s8 += vw * dpb[k];
+                        T[k] = valid ? Tn_ : T[k];
+                        ar[k] = valid ? nar : ar[k]; ag[k] = valid ? nag : ag[k]; ab[k] = valid ? nab : ab[k];
+                        lr[k] = valid ? b.z : lr[k]; lg[k] = valid ? b.w : lg[k]; lb[k] = valid ? cb : lb[k];
+                        lalpha[k] = valid ? alpha : lalpha[k];
+                    }
+                    if (__ballot(any_valid) == 0ull) continue;               // nobody accepted this splat: row stays 0
+                    s0 = bcast_lane63(wave_sum_to_lane63(s0)) * half_w;
+                    s1 = bcast_lane63(wave_sum_to_lane63(s1)) * half_h;
+                    s2 = bcast_lane63(wave_sum_to_lane63(s2)) * -0.5f;
+                    s3 = bcast_lane63(wave_sum_to_lane63(s3)) * -0.5f;
+                    s4 = bcast_lane63(wave_sum_to_lane63(s4)) * -0.5f;
+                    s5 = bcast_lane63(wave_sum_to_lane63(s5));
+                    s6 = bcast_lane63(wave_sum_to_lane63(s6));
+                    s7 = bcast_lane63(wave_sum_to_lane63(s7));
+                    s8 = bcast_lane63(wave_sum_to_lane63(s8));
+                    if (lane == j) { o0 = s0; o1 = s1; o2 = s2; o3 = s3; o4 = s4; o5 = s5; o6 = s6; o7 = s7; o8 = s8; }
+                }
+            }
+            if (lane < n) {
+                float4 *row = grad_rows + 3 * (size_t)slot;
+                row[0] = make_float4(o0, o1, o2, o3);
+                row[1] = make_float4(o4, o5, o6, o7);
+                row[2] = make_float4(o8, 0.f, 0.f, 0.f);
+            }
         }
     }
 }
 
-int launch_render_bwd(const FrameK &f, const gsr_camera &cam, const GeomWS &gw, BinningWS &bw, const ImageWS &iw,
-                      const float *dL_dcolor, bool debug, hipStream_t s)
+int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, int sort_result, const GeomWS &gw, BinningWS &bw,
+                      const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s)
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
-    if (n_tiles <= 0) return GSR_OK;
+    if (n_tiles <= 0 || chunks_run <= 0) return GSR_OK;
     ProfileScope prof("render_bwd", s);
-    hipLaunchKernelGGL(k_render_bwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, iw.ranges, bw.sorted_gid, bw.sorted_slot,
-                       gw.records, cam.bg, iw.final_T, iw.n_contrib, dL_dcolor, reinterpret_cast<float4 *>(bw.grad_rows));
+    hipLaunchKernelGGL(k_render_bwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, chunks_run, iw.ranges, bw.sorted_gid,
+                       bw.vals[sort_result], gw.records, cam.bg, iw.T_state, iw.last_enc, dL_dcolor,
+                       reinterpret_cast<float4 *>(bw.grad_rows));
     GSR_LAUNCH_CHECK("render_bwd", debug, s);
     return GSR_OK;
 }
 
-// ---- per-Gaussian reduction of the instance rows, in slot order (bitwise reproducible).
+// ---- per-Gaussian reduction of the instance rows, in slot order (bitwise reproducible).  One thread per
+// depth rank; Gaussians of chunks that never ran (or that met only closed tiles) have cnt_open = 0.
 constexpr int kRedBlock = 256;
-__global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int P, const uint32_t *__restrict__ tiles,
-                                                           const uint32_t *__restrict__ offsets,
+__global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int P, const uint32_t *__restrict__ order,
+                                                           const uint32_t *__restrict__ cnt_open,
+                                                           const uint32_t *__restrict__ row_begin,
                                                            const float4 *__restrict__ grad_rows, float4 *__restrict__ screen)
 {
-    const int i = blockIdx.x * kRedBlock + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t cnt = tiles[i];
+    const int r = blockIdx.x * kRedBlock + threadIdx.x;
+    if (r >= P) return;
+    const uint32_t g = order[r];
+    const uint32_t cnt = cnt_open[r];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     float a8 = 0.f;
     if (cnt) {
-        const uint32_t end = offsets[i];
-        for (uint32_t sl = end - cnt; sl < end; ++sl) {
+        const uint32_t begin = row_begin[r];
+        for (uint32_t sl = begin; sl < begin + cnt; ++sl) {
             const float4 r0 = grad_rows[3 * (size_t)sl], r1 = grad_rows[3 * (size_t)sl + 1];
             const float r2 = grad_rows[3 * (size_t)sl + 2].x;
             a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
@@ -311,17 +355,17 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int P, const uint32_t
             a8 += r2;
         }
     }
-    screen[3 * (size_t)i] = a0;
-    screen[3 * (size_t)i + 1] = a1;
-    screen[3 * (size_t)i + 2] = make_float4(a8, 0.f, 0.f, 0.f);
+    screen[3 * (size_t)g] = a0;
+    screen[3 * (size_t)g + 1] = a1;
+    screen[3 * (size_t)g + 2] = make_float4(a8, 0.f, 0.f, 0.f);
 }
 
 int launch_reduce_rows(const FrameK &f, const GeomWS &gw, const BinningWS &bw, float *screen_grads, bool debug, hipStream_t s)
 {
     if (f.P == 0) return GSR_OK;
     ProfileScope prof("reduce_rows", s);
-    hipLaunchKernelGGL(k_reduce_rows, dim3((f.P + kRedBlock - 1) / kRedBlock), dim3(kRedBlock), 0, s, f.P, gw.tiles_touched,
-                       gw.offsets, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads));
+    hipLaunchKernelGGL(k_reduce_rows, dim3((f.P + kRedBlock - 1) / kRedBlock), dim3(kRedBlock), 0, s, f.P, gw.order, gw.cnt_open,
+                       gw.row_begin, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads));
     GSR_LAUNCH_CHECK("reduce_rows", debug, s);
     return GSR_OK;
 }

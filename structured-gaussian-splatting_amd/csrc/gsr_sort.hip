@@ -1,0 +1,282 @@
+// gsr_sort.hip — hand-written device primitives for the binning stage:
+//   * inclusive prefix sum of u32 (three small kernels, host-known length)
+//   * stable LSD radix sort of (key, u32 value) pairs, 8-bit digits, FIXED grid, element count read from
+//     DEVICE memory (the progressive binning never tells the host how many instances a chunk emitted).
+//
+// Sort structure per pass (three launches): per-block digit histogram -> exclusive scan of the
+// [256][B] table -> stable scatter.  Block b owns the contiguous key range [b*per, (b+1)*per), walked in
+// sub-tiles of 1024 keys; inside a sub-tile wave w owns keys [256w, 256w+256) in 4 rounds of 64
+// consecutive keys, so (sub-tile, wave, round, lane) order == key order and the sort is stable.
+// Ranking inside a round is a wave64 match-any built from 8 ballots (one per digit bit) + popcount;
+// no LDS atomics are needed in the scatter, and the histogram uses one LDS atomic per wave when a
+// wave's 64 keys share a digit (the common case for the high tile-id digit) instead of 64.
+#include "gsr_internal.h"
+
+namespace gsr {
+
+// ------------------------------------------------------------------------------------ prefix sum
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanBlock * kScanItems;      // 2048 elements per block
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+// block-wide inclusive scan of one value per thread (256 threads); returns inclusive value, total in *total
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *sh_wave /*[4]*/, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) sh_wave[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kScanBlock / kWave; ++i) {
+        const uint32_t s = sh_wave[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return inc + base;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                           uint32_t *__restrict__ block_sums, int n)
+{
+    __shared__ uint32_t sh_wave[kScanBlock / kWave];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems], sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; sum += v[i]; }
+    uint32_t total;
+    uint32_t run = block_incl_scan(sum, sh_wave, &total) - sum;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) { run += v[i]; if (base + i < n) out[base + i] = run; }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// exclusive scan of the block sums, any count, one block
+__global__ __launch_bounds__(kScanBlock) void k_scan_tops(uint32_t *__restrict__ block_sums, int nb, uint32_t *__restrict__ grand_total)
+{
+    __shared__ uint32_t sh_wave[kScanBlock / kWave];
+    uint32_t carry = 0;
+    for (int base = 0; base < nb; base += kScanBlock) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nb ? block_sums[i] : 0u;
+        uint32_t total;
+        const uint32_t inc = block_incl_scan(v, sh_wave, &total);
+        if (i < nb) block_sums[i] = carry + inc - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && grand_total) *grand_total = carry;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ block_sums, int n)
+{
+    const uint32_t add = block_sums[blockIdx.x];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i)
+        if (base + i < n) out[base + i] += add;
+}
+
+size_t scan_temp_bytes(int n) { return align_up((size_t)((n + kScanTile - 1) / kScanTile + 1) * 4); }
+
+// out[i] = in[0] + ... + in[i]; optional *grand_total (device) = sum of all.
+int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const char *name,
+                          bool debug, hipStream_t s)
+{
+    if (n <= 0) {
+        if (grand_total) GSR_HIP_CHECK(hipMemsetAsync(grand_total, 0, 4, s));
+        return GSR_OK;
+    }
+    ProfileScope prof(name, s);
+    const int nb = (n + kScanTile - 1) / kScanTile;
+    uint32_t *sums = (uint32_t *)temp;
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kScanBlock), 0, s, in, out, sums, n);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(kScanBlock), 0, s, sums, nb, grand_total);
+    if (nb > 1) hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanBlock), 0, s, out, sums, n);
+    GSR_LAUNCH_CHECK(name, debug, s);
+    return GSR_OK;
+}
+
+// ------------------------------------------------------------------------------------ radix sort
+constexpr int kRadixBlock = 256;
+constexpr int kRadixBins = 256;
+constexpr int kRadixRounds = 4;                                  // 64-key rounds per wave per sub-tile
+constexpr int kRadixSubTile = kRadixBlock * kRadixRounds;        // 1024 keys
+
+__device__ __forceinline__ void block_range(uint32_t n, int nblocks, uint32_t &lo, uint32_t &hi)
+{
+    uint32_t per = (n + nblocks - 1) / nblocks;
+    per = (per + kRadixSubTile - 1) / kRadixSubTile * kRadixSubTile;
+    const uint64_t l = (uint64_t)blockIdx.x * per, h = l + per;
+    lo = l < n ? (uint32_t)l : n;
+    hi = h < n ? (uint32_t)h : n;
+}
+
+template <typename K>
+__global__ __launch_bounds__(kRadixBlock) void k_radix_hist(const K *__restrict__ keys, const uint32_t *__restrict__ n_ptr,
+                                                            uint32_t n_host, const uint32_t *__restrict__ base_ptr, int shift,
+                                                            uint32_t *__restrict__ table)
+{
+    __shared__ uint32_t hist[kRadixBins];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    if (base_ptr) keys += *base_ptr;
+    uint32_t lo, hi;
+    block_range(n, gridDim.x, lo, hi);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kRadixBlock) {
+        const uint32_t d = (uint32_t)(keys[i] >> shift) & 255u;
+        const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+        const unsigned long long same = __ballot(d == d0);
+        const unsigned long long act = __ballot(1);
+        if (same == act) {                                         // whole wave on one digit: one atomic
+            if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) atomicAdd(&hist[d0], (uint32_t)__popcll(act));
+        } else {
+            atomicAdd(&hist[d], 1u);
+        }
+    }
+    __syncthreads();
+    table[threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
+}
+
+// exclusive scan over the digit-major [256][B] table, one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t *__restrict__ table, int total)
+{
+    __shared__ uint32_t sh[1024];
+    const int per = (total + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(b + per, total);
+    uint32_t sum = 0;
+    for (int i = b; i < e; ++i) sum += table[i];
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                    // Hillis-Steele inclusive scan
+        const uint32_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - sum;
+    for (int i = b; i < e; ++i) { const uint32_t v = table[i]; table[i] = run; run += v; }
+}
+
+template <typename K>
+__global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                               K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                               const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                               const uint32_t *__restrict__ base_ptr, int shift,
+                                                               const uint32_t *__restrict__ table)
+{
+    if (base_ptr) {
+        const uint32_t bo = *base_ptr;
+        keys_in += bo; vals_in += bo; keys_out += bo; vals_out += bo;
+    }
+    __shared__ uint32_t base[kRadixBins];                          // next global position per digit for this block
+    __shared__ volatile uint32_t wave_cnt[kRadixBlock / kWave][kRadixBins];
+    __shared__ uint32_t offs[kRadixBlock / kWave][kRadixBins];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    base[threadIdx.x] = table[threadIdx.x * gridDim.x + blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < kRadixBlock / kWave; ++i) wave_cnt[i][threadIdx.x] = 0;
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    uint32_t lo, hi;
+    block_range(n, gridDim.x, lo, hi);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    __syncthreads();
+    for (uint32_t tile = lo; tile < hi; tile += kRadixSubTile) {
+        K key[kRadixRounds];
+        uint32_t local[kRadixRounds];
+#pragma unroll
+        for (int r = 0; r < kRadixRounds; ++r) {
+            const uint32_t idx = tile + w * (kWave * kRadixRounds) + r * kWave + lane;
+            const bool valid = idx < hi;
+            key[r] = valid ? keys_in[idx] : (K)0;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long m = __ballot((d >> bit) & 1u);
+                peers &= ((d >> bit) & 1u) ? m : ~m;
+            }
+            const uint32_t old = wave_cnt[w][d];
+            local[r] = old + (uint32_t)__popcll(peers & lt_mask);
+            if (valid && (peers & lt_mask) == 0ull) wave_cnt[w][d] = old + (uint32_t)__popcll(peers);
+        }
+        __syncthreads();
+        {                                                          // thread d: digit d's wave offsets
+            uint32_t run = base[threadIdx.x];
+#pragma unroll
+            for (int i = 0; i < kRadixBlock / kWave; ++i) {
+                const uint32_t c = wave_cnt[i][threadIdx.x];
+                offs[i][threadIdx.x] = run;
+                run += c;
+                wave_cnt[i][threadIdx.x] = 0;
+            }
+            base[threadIdx.x] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kRadixRounds; ++r) {
+            const uint32_t idx = tile + w * (kWave * kRadixRounds) + r * kWave + lane;
+            if (idx < hi) {
+                const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+                const uint32_t dst = offs[w][d] + local[r];
+                keys_out[dst] = key[r];
+                vals_out[dst] = vals_in[idx];
+            }
+        }
+        // the next sub-tile's first barrier orders these reads of offs[] before its rewrite
+    }
+}
+
+int radix_blocks(uint64_t n_max)
+{
+    uint64_t b = (n_max + 8191) / 8192;
+    if (b < 32) b = 32;
+    if (b > 1024) b = 1024;
+    return (int)b;
+}
+
+size_t radix_temp_bytes() { return align_up((size_t)kRadixBins * 1024 * 4); }
+
+// Sorts n (device *n_ptr if non-null, else n_host) pairs on key bits [begin_bit, end_bit).  buffers[0] holds
+// the input; *result = index of the buffer holding the output.  n_max bounds n on the host (grid sizing).
+template <typename K>
+int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
+                      const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,
+                      bool debug, hipStream_t s)
+{
+    *result = 0;
+    if (n_max == 0 || end_bit <= begin_bit) return GSR_OK;
+    ProfileScope prof(name, s);
+    const int B = radix_blocks(n_max);
+    uint32_t *table = (uint32_t *)temp;
+    int cur = 0;
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], n_ptr, n_host, base_ptr, shift, table);
+        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, table, kRadixBins * B);
+        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+                           vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, table);
+        cur ^= 1;
+    }
+    *result = cur;
+    GSR_LAUNCH_CHECK(name, debug, s);
+    return GSR_OK;
+}
+
+template int launch_radix_sort<uint32_t>(uint32_t *const[2], uint32_t *const[2], const uint32_t *, uint32_t, uint64_t,
+                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t);
+template int launch_radix_sort<uint64_t>(uint64_t *const[2], uint32_t *const[2], const uint32_t *, uint32_t, uint64_t,
+                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t);
+
+}  // namespace gsr

@@ -56,7 +56,12 @@ def _f32c(t: Optional[torch.Tensor], device=None) -> Optional[torch.Tensor]:
 
 class _Frame:
     """Native handles of one forward pass, kept alive by autograd's ctx for the backward."""
-    __slots__ = ("desc", "cam", "keep", "R", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device")
+    __slots__ = ("desc", "cam", "keep", "plan", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device")
+
+    @property
+    def R(self):
+        """num_rendered of the reference (upper bound of the instances this frame binned)."""
+        return int(self.plan.num_rendered)
 
 
 def _camera(rs: GaussianRasterizationSettings, device):
@@ -94,10 +99,10 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
     fr.image_ws = torch.empty(image_bytes, dtype=torch.uint8, device=device)
     fr.radii = torch.zeros(P, dtype=torch.int32, device=device)
     with torch.cuda.device(device):
-        fr.R = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device)
+        fr.plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device)
         fr.binning_ws = torch.empty(N.binning_size(fr.desc, fr.R), dtype=torch.uint8, device=device)
         color = out_color if out_color is not None else torch.zeros(3, H, W, dtype=torch.float32, device=device)
-        N.forward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.R, color, device)
+        N.forward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, color, device)
     return color, fr.radii, fr
 
 
@@ -109,7 +114,7 @@ def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.T
     if grad_color is None:
         return screen.zero_()[:P]
     with torch.cuda.device(fr.device):
-        N.backward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.R, grad_color, screen, fr.device)
+        N.backward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, grad_color, screen, fr.device)
     return screen[:P]
 
 

@@ -41,9 +41,19 @@ class Grads(C.Structure):
                 ("opacities", _f32p), ("scales", _f32p), ("rotations", _f32p), ("cov3D_precomp", _f32p)]
 
 
+MAX_CHUNKS = 8
+LAST_SHIFT = 26
+
+
+class FramePlan(C.Structure):
+    _fields_ = [("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("num_chunks", C.c_int32),
+                ("chunk_rank_begin", C.c_int32 * (MAX_CHUNKS + 1)), ("chunk_instances_max", C.c_int64 * MAX_CHUNKS),
+                ("chunks_run", C.c_int32), ("sort_result", C.c_int32), ("instances_emitted", C.c_int64)]
+
+
 class DebugViews(C.Structure):
-    _fields_ = [("splat_records", C.c_void_p), ("tiles_touched", C.c_void_p), ("point_offsets", C.c_void_p),
-                ("clamped", C.c_void_p), ("sorted_keys", C.c_void_p), ("sorted_gaussian", C.c_void_p),
+    _fields_ = [("splat_records", C.c_void_p), ("tiles_touched", C.c_void_p), ("depth_order", C.c_void_p),
+                ("point_offsets", C.c_void_p), ("clamped", C.c_void_p), ("sorted_gaussian", C.c_void_p),
                 ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p)]
 
 
@@ -121,21 +131,21 @@ def binning_size(desc: FrameDesc, R: int) -> int:
     return b.value
 
 
-def forward_preprocess(desc, cam: Camera, g: Gaussians, geom_ws, radii, device) -> int:
-    R = C.c_int64(0)
+def forward_preprocess(desc, cam: Camera, g: Gaussians, geom_ws, radii, device) -> FramePlan:
+    plan = FramePlan()
     _check(load().gsr_forward_preprocess(C.byref(desc), C.byref(cam), C.byref(g), _ptr(geom_ws), _ptr(radii),
-                                         C.byref(R), _stream(device)), "gsr_forward_preprocess")
-    return int(R.value)
+                                         C.byref(plan), _stream(device)), "gsr_forward_preprocess")
+    return plan
 
 
-def forward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, R, out_color, device):
+def forward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, plan: FramePlan, out_color, device):
     _check(load().gsr_forward_render(C.byref(desc), C.byref(cam), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws),
-                                     C.c_int64(R), _ptr(out_color), _stream(device)), "gsr_forward_render")
+                                     C.byref(plan), _ptr(out_color), _stream(device)), "gsr_forward_render")
 
 
-def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, R, dL_dcolor, screen_grads, device):
+def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, plan: FramePlan, dL_dcolor, screen_grads, device):
     _check(load().gsr_backward_render(C.byref(desc), C.byref(cam), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws),
-                                      C.c_int64(R), _ptr(dL_dcolor), _ptr(screen_grads), _stream(device)),
+                                      C.byref(plan), _ptr(dL_dcolor), _ptr(screen_grads), _stream(device)),
            "gsr_backward_render")
 
 
@@ -150,26 +160,27 @@ def mark_visible(means3D, viewmatrix, projmatrix, present):
                                    _ptr(present), _stream(means3D.device)), "gsr_mark_visible")
 
 
-def debug_views(desc, geom_ws, binning_ws, image_ws, R) -> dict:
+def debug_views(desc, geom_ws, binning_ws, image_ws, plan: FramePlan) -> dict:
     """Intermediate arrays as torch views INTO the workspaces (tests / profiling)."""
     v = DebugViews()
-    _check(load().gsr_debug_get_views(C.byref(desc), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws), C.c_int64(R),
+    _check(load().gsr_debug_get_views(C.byref(desc), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws), C.byref(plan),
                                       C.byref(v)), "gsr_debug_get_views")
-    P, N = desc.P, desc.width * desc.height
+    P, N, R = desc.P, desc.width * desc.height, int(plan.num_rendered)
     Tn = ((desc.width + 15) // 16) * ((desc.height + 15) // 16)
 
     def view(ws, addr, nbytes, dtype, shape):
-        if not addr or ws is None:
+        if not addr or ws is None or nbytes == 0:
             return None
         off = addr - ws.data_ptr()
         return ws[off:off + nbytes].view(dtype).view(shape)
     return dict(
         splat_records=view(geom_ws, v.splat_records, P * 48, torch.float32, (P, 12)),
         tiles_touched=view(geom_ws, v.tiles_touched, P * 4, torch.int32, (P,)),
+        depth_order=view(geom_ws, v.depth_order, P * 4, torch.int32, (P,)),
         point_offsets=view(geom_ws, v.point_offsets, P * 4, torch.int32, (P,)),
         clamped=view(geom_ws, v.clamped, P, torch.uint8, (P,)),
-        sorted_gaussian=view(binning_ws, v.sorted_gaussian, R * 4, torch.int32, (R,)) if R else None,
-        ranges=view(image_ws, v.ranges, Tn * 8, torch.int32, (Tn, 2)),
+        sorted_gaussian=view(binning_ws, v.sorted_gaussian, R * 4, torch.int32, (R,)),
+        ranges=view(image_ws, v.ranges, MAX_CHUNKS * Tn * 8, torch.int32, (MAX_CHUNKS, Tn, 2)),
         final_T=view(image_ws, v.final_T, N * 4, torch.float32, (desc.height, desc.width)),
         n_contrib=view(image_ws, v.n_contrib, N * 4, torch.int32, (desc.height, desc.width)))
 

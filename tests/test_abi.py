@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(native):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gsrast.h but not exported"
     assert set(native.EXPORTS) == declared
-    assert lib.gsr_version() == 1
+    assert lib.gsr_version() == 2
 
 
 def test_argument_validation_without_gpu(native):
@@ -40,14 +40,14 @@ def test_argument_validation_without_gpu(native):
     ok = native.make_desc(1000, 3, 16, 100, 60, 0.5, 0.5, 1.0, False, False)
     gb, ib = native.workspace_sizes(ok)
     assert gb >= 1000 * 57 and ib >= 100 * 60 * 8 + 7 * 4 * 8
-    assert native.binning_size(ok, 5000) >= 5000 * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 48)
+    assert native.binning_size(ok, 5000) >= 5000 * (4 * 6 + 48)
     with pytest.raises(native.GsrError, match="sh_coeffs"):
         native.workspace_sizes(native.make_desc(10, 1, 99, 64, 64, 0.5, 0.5, 1.0, False, False))
     # exactly-one-of rules are enforced at the ABI too (NULL device pointers are never dereferenced here)
     cam = native.Camera(1, 1, 1, 1)
     gs = native.Gaussians(1, None, None, 1, 1, 1, None)
-    R = C.c_int64(0)
-    rc = lib.gsr_forward_preprocess(C.byref(ok), C.byref(cam), C.byref(gs), C.c_void_p(1), C.c_void_p(1), C.byref(R), None)
+    plan = native.FramePlan()
+    rc = lib.gsr_forward_preprocess(C.byref(ok), C.byref(cam), C.byref(gs), C.c_void_p(1), C.c_void_p(1), C.byref(plan), None)
     assert rc == -1 and b"shs / colors_precomp" in lib.gsr_last_error()
 
 
