@@ -147,6 +147,19 @@ typedef struct gsr_debug_views {
 int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws,
                         const void *image_ws, const gsr_frame_plan *plan_host, gsr_debug_views *views);
 
+/* ---- the loss of the reference's timed window (train.py:104-105), fused.
+ * loss = (1 - lambda) * mean|image - target| + lambda * (1 - mean SSIM(image, target)), SSIM exactly as
+ * utils/loss_utils.py:33-63 (11x11 Gaussian window sigma 1.5, depthwise, zero padding, C1 = 1e-4, C2 = 9e-4).
+ * image/target: [channels, H, W] fp32.  forward writes out3 = (loss, l1, ssim) (device) and keeps the
+ * per-pixel SSIM derivatives in `workspace` for the backward; backward writes grad_image =
+ * upstream[0] * dloss/dimage (upstream: device scalar, NULL = 1). */
+int gsr_loss_workspace_size(int32_t channels, int32_t height, int32_t width, size_t *bytes);
+int gsr_loss_l1_ssim_forward(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *image,
+                             const float *target, void *workspace, float *out3, void *stream);
+int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *upstream,
+                              const float *image, const float *target, const void *workspace, float *grad_image,
+                              void *stream);
+
 /* Per-kernel device timing (hipEvent pairs recorded on the caller's stream around every kernel this
  * library launches, from any thread).  Off by default; the only process-wide state of the library,
  * mutex-protected, meant for benchmarks (one frame in flight).  gsr_profile_enable(1) resets the

@@ -59,7 +59,7 @@ class DebugViews(C.Structure):
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
            "gsr_forward_render", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
-           "gsr_profile_read")
+           "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward")
 
 _lib = None
 
@@ -198,3 +198,22 @@ def profile_read() -> dict:
     cnt = (C.c_int32 * n_max)()
     n = load().gsr_profile_read(n_max, names, ms, cnt)
     return {names[i].value.decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+
+def loss_workspace_size(C_, H, W) -> int:
+    b = C.c_size_t(0)
+    _check(load().gsr_loss_workspace_size(C.c_int32(C_), C.c_int32(H), C.c_int32(W), C.byref(b)), "gsr_loss_workspace_size")
+    return b.value
+
+
+def loss_forward(image, target, lam, workspace, out3):
+    Cn, H, W = image.shape
+    _check(load().gsr_loss_l1_ssim_forward(C.c_int32(Cn), C.c_int32(H), C.c_int32(W), C.c_float(lam), _ptr(image), _ptr(target),
+                                           _ptr(workspace), _ptr(out3), _stream(image.device)), "gsr_loss_l1_ssim_forward")
+
+
+def loss_backward(image, target, lam, upstream, workspace, grad_image):
+    Cn, H, W = image.shape
+    _check(load().gsr_loss_l1_ssim_backward(C.c_int32(Cn), C.c_int32(H), C.c_int32(W), C.c_float(lam), _ptr(upstream),
+                                            _ptr(image), _ptr(target), _ptr(workspace), _ptr(grad_image),
+                                            _stream(image.device)), "gsr_loss_l1_ssim_backward")

@@ -42,9 +42,45 @@ def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
     return m.mean() if size_average else m.mean(1).mean(1).mean(1)
 
 
-def training_loss(image, gt, lambda_dssim: float = 0.2):
-    """(1 - lambda) L1 + lambda (1 - SSIM), train.py:104-105 with arguments/__init__.py:89's default."""
+def training_loss_torch(image, gt, lambda_dssim: float = 0.2):
+    """(1 - lambda) L1 + lambda (1 - SSIM), train.py:104-105 with arguments/__init__.py:89's default,
+    in plain torch ops exactly as the reference composes it."""
     return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+
+
+class _FusedL1SSIM(torch.autograd.Function):
+    """The same loss as two HIP kernels (csrc/gsr_loss.hip) instead of 5 depthwise convolutions + their
+    backward; gradient flows to `image` only (the target is data)."""
+
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        from diff_gaussian_rasterization import _native as N
+        img = image.contiguous() if image.dtype == torch.float32 else image.float().contiguous()
+        tgt = gt.detach().contiguous() if gt.dtype == torch.float32 else gt.detach().float().contiguous()
+        ws = torch.empty(N.loss_workspace_size(*img.shape), dtype=torch.uint8, device=img.device)
+        out3 = torch.empty(3, dtype=torch.float32, device=img.device)
+        with torch.cuda.device(img.device):
+            N.loss_forward(img, tgt, float(lambda_dssim), ws, out3)
+        ctx.save_for_backward(img, tgt, ws)
+        ctx.lam = float(lambda_dssim)
+        return out3[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from diff_gaussian_rasterization import _native as N
+        img, tgt, ws = ctx.saved_tensors
+        grad = torch.empty_like(img)
+        up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(img.device):
+            N.loss_backward(img, tgt, ctx.lam, up, ws, grad)
+        return grad, None, None
+
+
+def training_loss(image, gt, lambda_dssim: float = 0.2):
+    """train.py:104-105.  On a HIP device: the fused kernels (image must be [C,H,W]); on the CPU: torch ops."""
+    if image.is_cuda and image.dim() == 3:
+        return _FusedL1SSIM.apply(image, gt, lambda_dssim)
+    return training_loss_torch(image, gt, lambda_dssim)
 
 
 def psnr(img1, img2):
