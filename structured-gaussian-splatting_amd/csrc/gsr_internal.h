@@ -97,6 +97,7 @@ struct ImageWS {                // O(N + Tn): the reference's imgBuffer
     uint2 *ranges;              // [GSR_MAX_CHUNKS][Tn]
     uint32_t *open;             // [Tn] 1 = tile still has an unsaturated pixel (0 outside the slab)
     uint32_t *sat;              // [(Gy+1)*(Gx+1)] summed-area table of `open`
+    uint32_t *sat_rows;         // same shape: row-prefix intermediate of the SAT build
     Ctrl *ctrl_scratch;         // stand-in control block for frames without a geometry workspace (P == 0)
     size_t total;
 };
@@ -117,8 +118,8 @@ ImageWS carve_image(void *base, const FrameK &f);
 BinningWS carve_binning(void *base, int64_t R);
 
 // ---- primitives (gsr_sort.hip)
-int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const char *name,
-                          bool debug, hipStream_t s);
+int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
+                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s);
 template <typename K>
 int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
                       const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,
@@ -137,7 +138,7 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s);
 int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, int sort_result, const GeomWS &gw, BinningWS &bw,
                       const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s);
-int launch_reduce_rows(const FrameK &f, const GeomWS &gw, const BinningWS &bw, float *screen_grads, bool debug,
+int launch_reduce_rows(const FrameK &f, int n_ranks, const GeomWS &gw, const BinningWS &bw, float *screen_grads, bool debug,
                        hipStream_t s);
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
                     const float *screen_grads, int g0, int g1, const gsr_grads &out, bool debug, hipStream_t s);

@@ -331,23 +331,27 @@ int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, in
     return GSR_OK;
 }
 
-// ---- per-Gaussian reduction of the instance rows, in slot order (bitwise reproducible).  One thread per
-// depth rank; Gaussians of chunks that never ran (or that met only closed tiles) have cnt_open = 0.
+// ---- per-Gaussian reduction of the instance rows (bitwise reproducible: fixed lane assignment and a fixed
+// shuffle tree).  EIGHT lanes cooperate on one depth rank (8 ranks per wave): lane i of the group sums rows
+// i, i+8, ... and three xor-shuffles combine the group.  The near, screen-filling Gaussians own hundreds of
+// rows each; one thread per Gaussian left a tail of a few thousand threads walking them serially.
+// Only ranks of chunks that actually ran can own rows; every other Gaussian's gradient row is zero (memset).
 constexpr int kRedBlock = 256;
-__global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int P, const uint32_t *__restrict__ order,
+constexpr int kRedGroup = 8;
+__global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const uint32_t *__restrict__ order,
                                                            const uint32_t *__restrict__ cnt_open,
                                                            const uint32_t *__restrict__ row_begin,
                                                            const float4 *__restrict__ grad_rows, float4 *__restrict__ screen)
 {
-    const int r = blockIdx.x * kRedBlock + threadIdx.x;
-    if (r >= P) return;
-    const uint32_t g = order[r];
-    const uint32_t cnt = cnt_open[r];
+    const int sub = threadIdx.x & (kRedGroup - 1);
+    const int r = (blockIdx.x * kRedBlock + threadIdx.x) / kRedGroup;
+    const bool live = r < n_ranks;
+    const uint32_t cnt = live ? cnt_open[r] : 0u;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
     float a8 = 0.f;
     if (cnt) {
         const uint32_t begin = row_begin[r];
-        for (uint32_t sl = begin; sl < begin + cnt; ++sl) {
+        for (uint32_t sl = begin + sub; sl < begin + cnt; sl += kRedGroup) {
             const float4 r0 = grad_rows[3 * (size_t)sl], r1 = grad_rows[3 * (size_t)sl + 1];
             const float r2 = grad_rows[3 * (size_t)sl + 2].x;
             a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
@@ -355,17 +359,30 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int P, const uint32_t
             a8 += r2;
         }
     }
-    screen[3 * (size_t)g] = a0;
-    screen[3 * (size_t)g + 1] = a1;
-    screen[3 * (size_t)g + 2] = make_float4(a8, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int off = kRedGroup / 2; off >= 1; off >>= 1) {
+        a0.x += __shfl_xor(a0.x, off); a0.y += __shfl_xor(a0.y, off); a0.z += __shfl_xor(a0.z, off); a0.w += __shfl_xor(a0.w, off);
+        a1.x += __shfl_xor(a1.x, off); a1.y += __shfl_xor(a1.y, off); a1.z += __shfl_xor(a1.z, off); a1.w += __shfl_xor(a1.w, off);
+        a8 += __shfl_xor(a8, off);
+    }
+    if (live && cnt && sub < 3) {
+        const uint32_t g = order[r];
+        screen[3 * (size_t)g + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : make_float4(a8, 0.f, 0.f, 0.f));
+    }
 }
 
-int launch_reduce_rows(const FrameK &f, const GeomWS &gw, const BinningWS &bw, float *screen_grads, bool debug, hipStream_t s)
+int launch_reduce_rows(const FrameK &f, int n_ranks, const GeomWS &gw, const BinningWS &bw, float *screen_grads, bool debug,
+                       hipStream_t s)
 {
     if (f.P == 0) return GSR_OK;
     ProfileScope prof("reduce_rows", s);
-    hipLaunchKernelGGL(k_reduce_rows, dim3((f.P + kRedBlock - 1) / kRedBlock), dim3(kRedBlock), 0, s, f.P, gw.order, gw.cnt_open,
-                       gw.row_begin, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads));
+    GSR_HIP_CHECK(hipMemsetAsync(screen_grads, 0, (size_t)f.P * kRowFloats * sizeof(float), s));
+    if (n_ranks > 0) {
+        const long long threads = (long long)n_ranks * kRedGroup;
+        hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((threads + kRedBlock - 1) / kRedBlock)), dim3(kRedBlock), 0, s, n_ranks,
+                           gw.order, gw.cnt_open, gw.row_begin, reinterpret_cast<const float4 *>(bw.grad_rows),
+                           reinterpret_cast<float4 *>(screen_grads));
+    }
     GSR_LAUNCH_CHECK("reduce_rows", debug, s);
     return GSR_OK;
 }

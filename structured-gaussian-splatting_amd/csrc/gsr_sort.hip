@@ -64,7 +64,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_local(const uint32_t *__res
 }
 
 // exclusive scan of the block sums, any count, one block
-__global__ __launch_bounds__(kScanBlock) void k_scan_tops(uint32_t *__restrict__ block_sums, int nb, uint32_t *__restrict__ grand_total)
+__global__ __launch_bounds__(kScanBlock) void k_scan_tops(uint32_t *__restrict__ block_sums, int nb, uint32_t *__restrict__ grand_total,
+                                                          const uint32_t *__restrict__ acc_in, uint32_t *__restrict__ acc_out)
 {
     __shared__ uint32_t sh_wave[kScanBlock / kWave];
     uint32_t carry = 0;
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_tops(uint32_t *__restrict__
         if (i < nb) block_sums[i] = carry + inc - v;
         carry += total;
     }
-    if (threadIdx.x == 0 && grand_total) *grand_total = carry;
+    if (threadIdx.x == 0) {
+        if (grand_total) *grand_total = carry;
+        if (acc_out) *acc_out = (acc_in ? *acc_in : 0u) + carry;      // running base of the next chunk
+    }
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ block_sums, int n)
@@ -91,18 +95,19 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(uint32_t *__restrict__ 
 size_t scan_temp_bytes(int n) { return align_up((size_t)((n + kScanTile - 1) / kScanTile + 1) * 4); }
 
 // out[i] = in[0] + ... + in[i]; optional *grand_total (device) = sum of all.
-int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const char *name,
-                          bool debug, hipStream_t s)
+int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
+                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s)
 {
     if (n <= 0) {
         if (grand_total) GSR_HIP_CHECK(hipMemsetAsync(grand_total, 0, 4, s));
+        if (acc_out && acc_in) GSR_HIP_CHECK(hipMemcpyAsync(acc_out, acc_in, 4, hipMemcpyDeviceToDevice, s));
         return GSR_OK;
     }
     ProfileScope prof(name, s);
     const int nb = (n + kScanTile - 1) / kScanTile;
     uint32_t *sums = (uint32_t *)temp;
     hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kScanBlock), 0, s, in, out, sums, n);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(kScanBlock), 0, s, sums, nb, grand_total);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(kScanBlock), 0, s, sums, nb, grand_total, acc_in, acc_out);
     if (nb > 1) hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanBlock), 0, s, out, sums, n);
     GSR_LAUNCH_CHECK(name, debug, s);
     return GSR_OK;
@@ -150,24 +155,25 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_hist(const K *__restrict_
     table[threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
 }
 
-// exclusive scan over the digit-major [256][B] table, one block of 1024 threads
-__global__ __launch_bounds__(1024) void k_radix_scan(uint32_t *__restrict__ table, int total)
+// Per-digit exclusive scan over the blocks: block d owns row d of the digit-major [256][B] table
+// (B <= 2048 = 256 threads x 8 entries) and writes the row total to totals[d].  The scatter kernel adds the
+// exclusive prefix of the 256 totals itself, so a pass stays at three launches.
+constexpr int kRadixMaxBlocks = 2048;
+__global__ __launch_bounds__(kRadixBlock) void k_radix_scan(uint32_t *__restrict__ table, int B, uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t sh[1024];
-    const int per = (total + 1023) / 1024;
-    const int b = threadIdx.x * per, e = min(b + per, total);
-    uint32_t sum = 0;
-    for (int i = b; i < e; ++i) sum += table[i];
-    sh[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {                    // Hillis-Steele inclusive scan
-        const uint32_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0u;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t run = sh[threadIdx.x] - sum;
-    for (int i = b; i < e; ++i) { const uint32_t v = table[i]; table[i] = run; run += v; }
+    __shared__ uint32_t sh_wave[kRadixBlock / kWave];
+    uint32_t *row = table + (size_t)blockIdx.x * B;
+    const int per = (B + kRadixBlock - 1) / kRadixBlock;            // <= 8
+    const int b0 = threadIdx.x * per;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = (i < per && b0 + i < B) ? row[b0 + i] : 0u; sum += v[i]; }
+    uint32_t total;
+    uint32_t run = block_incl_scan(sum, sh_wave, &total) - sum;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (i < per && b0 + i < B) { row[b0 + i] = run; run += v[i]; }
+    if (threadIdx.x == 0) totals[blockIdx.x] = total;
 }
 
 template <typename K>
@@ -175,7 +181,8 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
                                                                K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                                const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                                const uint32_t *__restrict__ base_ptr, int shift,
-                                                               const uint32_t *__restrict__ table)
+                                                               const uint32_t *__restrict__ table,
+                                                               const uint32_t *__restrict__ totals)
 {
     if (base_ptr) {
         const uint32_t bo = *base_ptr;
@@ -184,8 +191,14 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
     __shared__ uint32_t base[kRadixBins];                          // next global position per digit for this block
     __shared__ volatile uint32_t wave_cnt[kRadixBlock / kWave][kRadixBins];
     __shared__ uint32_t offs[kRadixBlock / kWave][kRadixBins];
+    __shared__ uint32_t sh_wave[kRadixBlock / kWave];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    base[threadIdx.x] = table[threadIdx.x * gridDim.x + blockIdx.x];
+    {
+        const uint32_t tot = totals[threadIdx.x];
+        uint32_t all;
+        const uint32_t digit_excl = block_incl_scan(tot, sh_wave, &all) - tot;
+        base[threadIdx.x] = digit_excl + table[threadIdx.x * gridDim.x + blockIdx.x];
+    }
 #pragma unroll
     for (int i = 0; i < kRadixBlock / kWave; ++i) wave_cnt[i][threadIdx.x] = 0;
     const uint32_t n = n_ptr ? *n_ptr : n_host;
@@ -241,13 +254,13 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
 
 int radix_blocks(uint64_t n_max)
 {
-    uint64_t b = (n_max + 8191) / 8192;
-    if (b < 32) b = 32;
-    if (b > 1024) b = 1024;
+    uint64_t b = (n_max + 2047) / 2048;          // ~2 sub-tiles per block: enough blocks to fill 256 CUs early
+    if (b < 64) b = 64;
+    if (b > kRadixMaxBlocks) b = kRadixMaxBlocks;
     return (int)b;
 }
 
-size_t radix_temp_bytes() { return align_up((size_t)kRadixBins * 1024 * 4); }
+size_t radix_temp_bytes() { return align_up((size_t)kRadixBins * kRadixMaxBlocks * 4) + align_up(kRadixBins * 4); }
 
 // Sorts n (device *n_ptr if non-null, else n_host) pairs on key bits [begin_bit, end_bit).  buffers[0] holds
 // the input; *result = index of the buffer holding the output.  n_max bounds n on the host (grid sizing).
@@ -261,12 +274,13 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
     ProfileScope prof(name, s);
     const int B = radix_blocks(n_max);
     uint32_t *table = (uint32_t *)temp;
+    uint32_t *totals = (uint32_t *)((char *)temp + align_up((size_t)kRadixBins * kRadixMaxBlocks * 4));
     int cur = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         hipLaunchKernelGGL(k_radix_hist<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], n_ptr, n_host, base_ptr, shift, table);
-        hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(1024), 0, s, table, kRadixBins * B);
+        hipLaunchKernelGGL(k_radix_scan, dim3(kRadixBins), dim3(kRadixBlock), 0, s, table, B, totals);
         hipLaunchKernelGGL(k_radix_scatter<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
-                           vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, table);
+                           vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, table, totals);
         cur ^= 1;
     }
     *result = cur;
