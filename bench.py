@@ -31,19 +31,24 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def algorithmic_bytes(P, V, R, N, Tn, K, M):
-    """Per-kernel ALGORITHMIC bytes of one step (each logical array counted once per
-    read and once per write).  Keys are the library's profile names."""
+def algorithmic_bytes(P, V, Re, N, Tn, K, M, Vlive, C=3):
+    """ALGORITHMIC bytes per step and kernel: SURVEY.md 8d's per-unit figures x the units each kernel
+    processes in THIS design.  Re = instances actually emitted by the progressive
+    binning (the reference would process R = num_rendered of them), Vlive = Gaussians with a non-zero
+    screen-space gradient.  Keys are the library's profile names; values are totals per step."""
     return {
-        "preprocess": 44 * P + 12 * K * V + 8 * P + 67 * V,
-        "scan": 8 * P,
-        "duplicate": 4 * P + 16 * V + 12 * R,
-        "radix_sort": 24 * R,                       # algorithmic minimum: one read + one write of (key, value)
-        "ranges": 8 * R + 8 * Tn,
-        "render_fwd": 40 * R + 12 + 20 * N,
-        "render_bwd": 36 * P + 40 * R + 20 * N + 36 * R,
-        "reduce_rows": 36 * R + 36 * P,            # this design's deterministic reduction (replaces atomics RMW)
-        "geom_bwd": 4 * P + (99 + 12 * K) * V + (40 + 12 * M) * P,
+        "preprocess": 52 * P + (12 * K + 67) * V,          # K1 (+ 8 B/Gaussian depth-sort key/value)
+        "depth_sort": 16 * P,                               # minimum: one read + one write of (key, value)
+        "gather_tiles": 12 * P, "scan_tiles": 8 * P, "chunk_plan": 0, "open_sat": 8 * Tn,
+        "count_open": 56 * V, "scan_open": 8 * V,
+        "emit": 12 * Re,                                    # K3: key 4 + slot 4 + Gaussian 4 per instance
+        "tile_sort": 16 * Re,                               # K4 minimum: one read + one write of (tile, slot)
+        "ranges": 16 * Re + 8 * Tn,                         # K5 (+ sorted position -> Gaussian)
+        "render_fwd": 40 * Re + 20 * N,                     # K6: id 4 + record 36 per instance; 20 B/px
+        "render_bwd": 76 * Re + 20 * N,                     # K7: 40 read + 36 written per instance; 20 B/px
+        "reduce_rows": 36 * Re + 36 * P,                    # deterministic reduction (replaces atomic RMW)
+        "geom_bwd": 4 * P + (99 + 12 * K) * Vlive + (40 + 12 * M) * P,   # K8 + K9
+        "loss_fwd": 20 * C * N, "loss_bwd": 24 * C * N,
     }
 
 
@@ -130,20 +135,28 @@ def main():
     V = int((radii > 0).sum())
     Npix, Tn = cfg["W"] * cfg["H"], ((cfg["W"] + 15) // 16) * ((cfg["H"] + 15) // 16)
     K = M = (cfg["D"] + 1) ** 2
-    R = int(getattr(render, "last_num_rendered", 0)) or _num_rendered(model, cam, bg, pipe)
-    alg = algorithmic_bytes(P, V, R, Npix, Tn, K, M)
-    per_kernel = {k: dict(ms=ms / max(n, 1), launches_per_step=n / args.steps,
-                          alg_GBs=(alg.get(k, 0) / 1e9) / (ms / max(n, 1) / 1e3) if ms > 0 else None)
-                  for k, (ms, n) in prof.items()}
+    stats = _frame_stats(model, cam, bg, pipe)
+    R, Re, Vlive, pairs = stats["num_rendered"], stats["emitted"], stats["live"], stats["pairs_bwd"]
+    alg = algorithmic_bytes(P, V, Re, Npix, Tn, K, M, Vlive)
+    per_kernel = {}
+    for k, (ms, n) in prof.items():
+        per_step_ms = ms / args.steps
+        per_kernel[k] = dict(ms_per_step=per_step_ms, launches_per_step=n / args.steps,
+                             alg_GBs=(alg.get(k, 0) / 1e9) / (per_step_ms / 1e3) if per_step_ms > 0 else None)
     raster_ms = sum(ms for ms, _ in prof.values()) / args.steps
     dom = max(prof, key=lambda k: prof[k][0])
-    dom_ms = prof[dom][0] / max(prof[dom][1], 1)
-    achieved = (alg[dom] / 1e9) / (dom_ms / 1e3)
+    launches = max(prof[dom][1], 1)
+    dom_ms = prof[dom][0] / launches                              # average duration of one launch
+    bytes_per_launch = alg[dom] * args.steps / launches
+    achieved = (bytes_per_launch / 1e9) / (dom_ms / 1e3)
     roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=_traffic_from_profiles(dom),
-                    avg_launch_ms=round(dom_ms, 4), algorithmic_bytes_per_launch=int(alg[dom]),
+                    avg_launch_ms=round(dom_ms, 4), algorithmic_bytes_per_launch=int(bytes_per_launch),
                     step_algorithmic_bytes=int(sum(alg.values())),
-                    step_frac=round(sum(alg.values()) / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 5))
+                    step_frac=round(sum(alg.values()) / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 5),
+                    note="blend kernels are VALU-bound (SURVEY 8d caveat): secondary rate = "
+                         f"{pairs / 1e9 / (per_kernel.get('render_bwd', {}).get('ms_per_step', 0) / 1e3 + 1e-12):.1f} "
+                         "G (pixel,splat) pairs/s in render_bwd")
 
     if rank != 0:
         if dist is not None:
@@ -163,7 +176,8 @@ def main():
         "config": {"workload": f"{args.workload}: {P} Gaussians, {cfg['W']}x{cfg['H']}, SH degree {cfg['D']} "
                                f"(SURVEY Appendix B seed {cfg['seed']}); step = render() + L1/D-SSIM loss + backward "
                                f"(train.py:79-108 window)",
-                   "visible": V, "num_rendered": R, "parallelism": "single" if world == 1 else f"tile-row slabs x{world}"},
+                   "visible": V, "num_rendered": R, "instances_emitted": Re, "chunks_run": stats["chunks_run"],
+                   "parallelism": "single" if world == 1 else f"tile-row slabs x{world}"},
         "raster_ms_per_step": round(raster_ms, 4),
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                     for k, v in per_kernel.items()},
@@ -175,11 +189,13 @@ def main():
         dist.destroy_process_group()
 
 
-def _num_rendered(model, cam, bg, pipe):
-    """R of the benchmark frame (one extra un-timed forward through the functional API)."""
+def _frame_stats(model, cam, bg, pipe):
+    """Workload statistics of the benchmark frame (one extra un-timed forward/backward through the functional
+    API): R, instances emitted, chunks run, Gaussians with a non-zero screen gradient, (pixel, splat) pairs."""
     import math
 
     import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _native as N
     with torch.no_grad():
         rs = dgr.GaussianRasterizationSettings(cam.image_height, cam.image_width, math.tan(cam.FoVx * .5),
                                                math.tan(cam.FoVy * .5), bg, 1.0, cam.world_view_transform,
@@ -187,7 +203,25 @@ def _num_rendered(model, cam, bg, pipe):
                                                False, False)
         _, _, fr = dgr.rasterize_forward(model.get_xyz, model.get_features, None, model.get_opacity, model.get_scaling,
                                          model.get_rotation, None, rs)
-    return fr.R
+        v = N.debug_views(fr.desc, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan)
+        rng = v["ranges"].long()[:fr.plan.chunks_run]
+        lens = rng[..., 1] - rng[..., 0]
+        emitted = int(lens.sum())
+        # pairs the backward evaluates: per pixel, its last contributor's position in the concatenated list
+        enc = v["n_contrib"].long()
+        c = (enc >> N.LAST_SHIFT) - 1
+        pos = enc & ((1 << N.LAST_SHIFT) - 1)
+        H, W = enc.shape
+        Gx = (W + 15) // 16
+        ys, xs = torch.meshgrid(torch.arange(H, device=enc.device), torch.arange(W, device=enc.device), indexing="ij")
+        tile = (ys // 16) * Gx + xs // 16
+        before = torch.cat([torch.zeros_like(lens[:1]), torch.cumsum(lens, 0)], 0)
+        ncontrib = torch.where(c >= 0, before[c.clamp(min=0), tile] + pos, torch.zeros_like(pos))
+        g = torch.ones(3, H, W, device=enc.device)
+        screen = dgr.rasterize_backward_screen(fr, g)
+        live = int((screen.abs().sum(1) > 0).sum())
+    return dict(num_rendered=fr.R, emitted=emitted, chunks_run=int(fr.plan.chunks_run), live=live,
+                pairs_bwd=int(ncontrib.sum()))
 
 
 def _traffic_from_profiles(kernel):
