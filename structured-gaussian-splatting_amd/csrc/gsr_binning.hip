@@ -11,9 +11,10 @@
 //   2. inclusive scan of tiles touched in depth order; plan depth chunks with cumulative instance
 //      targets R/16, R/4, R (first chunk at least 1 M instances): every chunk costs ~16 small launches
 //      (~100 us of fixed time) while an instance costs ~0.1 ns, so few and large chunks win    [P-sized]
-//   3. per chunk: count instances that fall into OPEN tiles (O(1) per Gaussian through a summed-area
-//      table of the open flags), scan, emit (tile id, slot) pairs in depth order, stable radix sort on the
-//      tile id only (2 passes of 8 bits), tile ranges, blend (gsr_render.hip), rebuild open flags + SAT.
+//   3. per chunk: count the instances each Gaussian emits (tiles of its rectangle that are OPEN and that its
+//      alpha >= 1/255 ellipse can reach: exact tile culling), scan, emit (tile id, slot) pairs in depth
+//      order, stable radix sort on the tile id only (2 passes of 8 bits), tile ranges, blend
+//      (gsr_render.hip), recount the open tiles.
 //      The host reads back ONE word per chunk (open tiles left) and stops when it is zero.
 //
 // A tile is closed only when every pixel has taken the A.8 cut-off, after which no further splat can
@@ -63,8 +64,6 @@ ImageWS carve_image(void *base, const FrameK &f)
     w.last_enc = (int32_t *)(b + o); o += align_up((N ? N : 1) * 4);
     w.ranges = (uint2 *)(b + o); o += align_up((Tn ? Tn : 1) * 8 * GSR_MAX_CHUNKS);
     w.open = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
-    w.sat = (uint32_t *)(b + o); o += align_up((size_t)(f.Gx + 1) * (f.Gy + 1) * 4);
-    w.sat_rows = (uint32_t *)(b + o); o += align_up((size_t)(f.Gx + 1) * (f.Gy + 1) * 4);
     w.ctrl_scratch = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
     w.total = o;
     return w;
@@ -164,46 +163,23 @@ int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
     return GSR_OK;
 }
 
-// ---- open flags + summed-area table.  One block; Tn is a few thousand to a few ten-thousand tiles.
-// sat[y][x] = number of open tiles in rows < y and columns < x   (dimensions (Gy+1) x (Gx+1)).
-__global__ __launch_bounds__(1024) void k_open_sat(FrameK f, int init, uint32_t *__restrict__ open, uint32_t *__restrict__ sat,
-                                                   uint32_t *__restrict__ rowp, Ctrl *ctrl)
+// ---- open flags: (re)initialise for the slab, count the tiles that are still open (one block).
+__global__ __launch_bounds__(1024) void k_open_count(FrameK f, int init, uint32_t *__restrict__ open, Ctrl *ctrl)
 {
     __shared__ uint32_t sh_count;
-    const int Gx = f.Gx, Gy = f.Gy, S = Gx + 1;
     if (threadIdx.x == 0) sh_count = 0;
     __syncthreads();
-    if (init)
-        for (int t = threadIdx.x; t < Gx * Gy; t += blockDim.x) {
-            const int ty = t / Gx;
+    uint32_t mine = 0;
+    for (int t = threadIdx.x; t < f.Gx * f.Gy; t += blockDim.x) {
+        if (init) {
+            const int ty = t / f.Gx;
             open[t] = (ty >= f.ty0 && ty < f.ty1) ? 1u : 0u;
         }
-    __syncthreads();
-    // row-wise prefix: one WAVE per tile row (coalesced 64-wide loads + wave scan), then column-wise prefix:
-    // one thread per column walking down the rows (adjacent threads touch adjacent addresses)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int y = wv; y <= Gy; y += nw) {
-        uint32_t carry = 0;
-        if (lane == 0) rowp[y * S] = 0;
-        for (int x0 = 0; x0 < Gx; x0 += kWave) {
-            const int x = x0 + lane;
-            uint32_t v = (y > 0 && x < Gx) ? open[(y - 1) * Gx + x] : 0u;
+        mine += open[t];
+    }
 #pragma unroll
-            for (int off = 1; off < kWave; off <<= 1) {
-                const uint32_t t = __shfl_up(v, off);
-                if (lane >= off) v += t;
-            }
-            if (x < Gx) rowp[y * S + x + 1] = carry + v;
-            carry += __shfl(v, kWave - 1);
-        }
-        if (lane == 0 && y > 0) atomicAdd(&sh_count, carry);
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x <= Gx; x += blockDim.x) {
-        uint32_t run = 0;
-#pragma unroll 8
-        for (int y = 0; y <= Gy; ++y) { run += rowp[y * S + x]; sat[y * S + x] = run; }
-    }
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sh_count, mine);
     __syncthreads();
     if (threadIdx.x == 0) ctrl->open_count = sh_count;
 }
@@ -212,37 +188,56 @@ int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hi
 {
     const size_t Tn = (size_t)f.Gx * f.Gy;
     GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, Tn * sizeof(uint2) * GSR_MAX_CHUNKS, s));
-    ProfileScope prof("open_sat", s);
-    hipLaunchKernelGGL(k_open_sat, dim3(1), dim3(1024), 0, s, f, 1, iw.open, iw.sat, iw.sat_rows, gw.ctrl);
-    GSR_LAUNCH_CHECK("open_sat(init)", debug, s);
+    ProfileScope prof("open_count", s);
+    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 1, iw.open, gw.ctrl);
+    GSR_LAUNCH_CHECK("open_count(init)", debug, s);
     return GSR_OK;
 }
 
 int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
 {
-    ProfileScope prof("open_sat", s);
-    hipLaunchKernelGGL(k_open_sat, dim3(1), dim3(1024), 0, s, f, 0, iw.open, iw.sat, iw.sat_rows, gw.ctrl);
-    GSR_LAUNCH_CHECK("open_sat", debug, s);
+    ProfileScope prof("open_count", s);
+    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 0, iw.open, gw.ctrl);
+    GSR_LAUNCH_CHECK("open_count", debug, s);
     return GSR_OK;
 }
 
-// ---- per chunk: count instances into open tiles (SAT: O(1) per Gaussian)
+// ---- per chunk: count the instances each Gaussian will emit: tiles of its rectangle that are still open AND
+// that its alpha >= 1/255 ellipse can reach (tile_may_contribute: exact culling, no pixel changes).  One WAVE
+// per Gaussian, 64 tiles per step, so screen-filling splats do not serialise on a lane.
+__device__ __forceinline__ bool instance_wanted(const FrameK &f, const TileRect &t, int w, int i, int total,
+                                                const float4 &a, const float4 &b, const uint32_t *__restrict__ open,
+                                                uint32_t &tile)
+{
+    if (i >= total) return false;
+    const int tx = t.x0 + i % w, ty = t.y0 + i / w;
+    tile = (uint32_t)(ty * f.Gx + tx);
+    return open[tile] != 0u && tile_may_contribute(a.x, a.y, a.z, a.w, b.x, b.y, tx, ty);
+}
+
 __global__ __launch_bounds__(kBinBlock) void k_count_open(FrameK f, int r0, int r1, const uint32_t *__restrict__ order,
-                                                          const float4 *__restrict__ records, const uint32_t *__restrict__ sat,
+                                                          const float4 *__restrict__ records, const uint32_t *__restrict__ open,
                                                           const Ctrl *__restrict__ ctrl, int chunk, uint32_t *__restrict__ cnt_open)
 {
-    const int r = r0 + blockIdx.x * kBinBlock + threadIdx.x;
-    if (r >= r1) return;
-    if (chunk > 0 && ctrl->open_count == 0u) { cnt_open[r] = 0; return; }   // speculatively enqueued chunk: all tiles closed
-    const uint32_t g = order[r];
-    const float4 a = records[3 * (size_t)g], c = records[3 * (size_t)g + 2];
-    TileRect t = tile_rect(a.x, a.y, c.z, f);
-    slab_clip(t, f);
-    const int S = f.Gx + 1;
-    uint32_t cnt = 0;
-    if (t.x1 > t.x0 && t.y1 > t.y0)
-        cnt = sat[t.y1 * S + t.x1] - sat[t.y0 * S + t.x1] - sat[t.y1 * S + t.x0] + sat[t.y0 * S + t.x0];
-    cnt_open[r] = cnt;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * kBinBlock + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * kBinBlock) >> 6;
+    const bool nothing_open = chunk > 0 && ctrl->open_count == 0u;
+    for (int r = r0 + wave; r < r1; r += n_waves) {
+        uint32_t cnt = 0;
+        if (!nothing_open) {
+            const uint32_t g = order[r];
+            const float4 a = records[3 * (size_t)g], b = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
+            TileRect t = tile_rect(a.x, a.y, cc.z, f);
+            slab_clip(t, f);
+            const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0);
+            for (int i0 = 0; i0 < total; i0 += kWave) {
+                uint32_t tile;
+                cnt += (uint32_t)__popcll(__ballot(instance_wanted(f, t, w, i0 + lane, total, a, b, open, tile)));
+            }
+        }
+        if (lane == 0) cnt_open[r] = cnt;
+    }
 }
 
 // ---- emit (tile, slot) pairs of the chunk's Gaussians in depth order, open tiles only.  One WAVE walks one
@@ -269,19 +264,14 @@ __global__ __launch_bounds__(kBinBlock) void k_emit(FrameK f, int c, int r0, int
         if (lane == 0) row_begin[r] = first;
         if (cnt == 0) continue;
         const uint32_t g = order[r];
-        const float4 a = records[3 * (size_t)g], cc = records[3 * (size_t)g + 2];
+        const float4 a = records[3 * (size_t)g], b = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
         TileRect t = tile_rect(a.x, a.y, cc.z, f);
         slab_clip(t, f);
         const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0);
         uint32_t emitted = 0;
         for (int i0 = 0; i0 < total; i0 += kWave) {
-            const int i = i0 + lane;
             uint32_t tile = 0;
-            bool is_open = false;
-            if (i < total) {
-                tile = (uint32_t)((t.y0 + i / w) * f.Gx + t.x0 + i % w);
-                is_open = open[tile] != 0;
-            }
+            const bool is_open = instance_wanted(f, t, w, i0 + lane, total, a, b, open, tile);
             const unsigned long long m = __ballot(is_open);
             if (is_open) {
                 const uint32_t slot = first + emitted + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -329,8 +319,10 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     const size_t Tn = (size_t)f.Gx * f.Gy;
     {
         ProfileScope prof("count_open", s);
-        hipLaunchKernelGGL(k_count_open, dim3((n + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, s, f, r0, r1, gw.order,
-                           gw.records, iw.sat, gw.ctrl, c, gw.cnt_open);
+        int cblocks = (n + 3) / 4;                    // one wave per Gaussian per step
+        if (cblocks > 4096) cblocks = 4096;
+        hipLaunchKernelGGL(k_count_open, dim3(cblocks), dim3(kBinBlock), 0, s, f, r0, r1, gw.order, gw.records, iw.open,
+                           gw.ctrl, c, gw.cnt_open);
         GSR_LAUNCH_CHECK("count_open", debug, s);
     }
     if ((rc = launch_scan_inclusive(gw.cnt_open + r0, gw.offs_open + r0, n, gw.scan_temp, &gw.ctrl->chunk_R[c],

@@ -96,8 +96,6 @@ struct ImageWS {                // O(N + Tn): the reference's imgBuffer
     int32_t *last_enc;          // [N]  (chunk + 1) << 26 | contributor position in that chunk's range
     uint2 *ranges;              // [GSR_MAX_CHUNKS][Tn]
     uint32_t *open;             // [Tn] 1 = tile still has an unsaturated pixel (0 outside the slab)
-    uint32_t *sat;              // [(Gy+1)*(Gx+1)] summed-area table of `open`
-    uint32_t *sat_rows;         // same shape: row-prefix intermediate of the SAT build
     Ctrl *ctrl_scratch;         // stand-in control block for frames without a geometry workspace (P == 0)
     size_t total;
 };

@@ -49,6 +49,38 @@ GSR_HD TileRect tile_rect(float px, float py, float radius, const FrameK &f)
     return r;
 }
 
+// ---- exact tile culling.  Returns false only when NO pixel of tile (tile_x, tile_y) can pass the blend's
+// acceptance test (power <= 0 and alpha = min(0.99, op * exp(power)) >= 1/255, A.8) for this splat, so dropping
+// the (tile, splat) instance changes no pixel and no gradient.  The maximum of the concave quadratic
+// power(d) = -1/2 (A dx^2 + C dy^2) - B dx dy over the tile's pixel-centre rectangle (a superset of its 256
+// pixels) is compared with the power at which alpha reaches 1/255, minus a margin that covers the blend
+// kernels' fp32 evaluation error (few 1e-7 of the term magnitudes) and their exp2-based exponential (1e-6).
+GSR_HD bool tile_may_contribute(float sx, float sy, float A, float B, float C, float op, int tile_x, int tile_y)
+{
+    if (op < (float)GSR_ALPHA_MIN) return false;             // op * G <= op < 1/255 for every G <= 1
+    if (!(A > 0.f) || !(C > 0.f) || !(A * C - B * B > 0.f)) return true;     // not a proper ellipse: keep
+    // d = splat - pixel, pixel in [16 t, 16 t + 15]
+    const float dx0 = sx - (float)(tile_x * GSR_TILE + GSR_TILE - 1), dx1 = sx - (float)(tile_x * GSR_TILE);
+    const float dy0 = sy - (float)(tile_y * GSR_TILE + GSR_TILE - 1), dy1 = sy - (float)(tile_y * GSR_TILE);
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;   // centre inside the rectangle
+    float qmax = -3.0e38f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e < 2; ++e) {
+        const float ex = e ? dx1 : dx0;                         // edge dx = ex, dy free
+        float dy = fminf(dy1, fmaxf(dy0, -B * ex / C));
+        qmax = fmaxf(qmax, -0.5f * (A * ex * ex + C * dy * dy) - B * ex * dy);
+        const float ey = e ? dy1 : dy0;                         // edge dy = ey, dx free
+        float dx = fminf(dx1, fmaxf(dx0, -B * ey / A));
+        qmax = fmaxf(qmax, -0.5f * (A * dx * dx + C * ey * ey) - B * dx * ey);
+    }
+    const float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1));
+    const float S = 0.5f * A * mx * mx + 0.5f * C * my * my + fabsf(B) * mx * my;
+    const float need = -logf(255.f * op);                       // power at which op * exp(power) = 1/255
+    return qmax >= need - (0.01f + 1e-5f * S);
+}
+
 GSR_HD void slab_clip(TileRect &r, const FrameK &f)
 {
     if (r.y0 < f.ty0) r.y0 = f.ty0;

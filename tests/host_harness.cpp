@@ -59,3 +59,9 @@ extern "C" void hh_geom_backward(int P, int D, int M, int W, int H, float tanfov
         for (int k = 0; k < 6; ++k) dcov[6 * i + k] = g.dcov[k];
     }
 }
+
+extern "C" void hh_tile_may_contribute(int n, const float *sx, const float *sy, const float *A, const float *B, const float *C,
+                                       const float *op, const int32_t *tx, const int32_t *ty, uint8_t *out)
+{
+    for (int i = 0; i < n; ++i) out[i] = tile_may_contribute(sx[i], sy[i], A[i], B[i], C[i], op[i], tx[i], ty[i]) ? 1 : 0;
+}

@@ -193,23 +193,40 @@ def test_intermediates_bit_exact_vs_oracle_f32():
     # per-tile lists
     Tn = fr.Gx * fr.Gy
     lists, lens = _per_tile_lists(v, frame.plan, Tn)
-    nc_full = np.zeros((fr.Gy * 16, fr.Gx * 16), np.int64)
-    nc_full[:fr.H, :fr.W] = fr.n_contrib
-    tile_max = nc_full.reshape(fr.Gy, 16, fr.Gx, 16).max((1, 3)).reshape(-1)
-    n_bad = 0
+    # With exact tile culling the device list is a SUBSEQUENCE of the oracle's list (instances whose
+    # alpha >= 1/255 ellipse cannot reach the tile are never emitted), in the same order.
+    def is_subsequence(sub, full):
+        j = 0
+        for x in full:
+            if j < sub.size and sub[j] == x:
+                j += 1
+        return j == sub.size
+    n_bad, n_emitted, n_full = 0, 0, 0
     for t in range(Tn):
         want = fr.point_list[fr.ranges[t, 0]:fr.ranges[t, 1]]
         got = lists[t]
-        assert got.size <= want.size and got.size >= tile_max[t], (t, got.size, want.size, tile_max[t])
-        n_bad += int((got != want[:got.size]).sum())
-    assert n_bad <= 1e-3 * max(sum(l.size for l in lists), 1)
+        n_emitted += got.size; n_full += want.size
+        if not is_subsequence(got, want):
+            n_bad += 1                      # only possible through depth-ulp reorderings
+    assert n_bad <= max(2, Tn // 100), n_bad
+    assert n_emitted < n_full
     vis = fr.radii > 0
     np.testing.assert_allclose(rec[vis, 0:2], fr.xy[vis], rtol=1e-6, atol=2e-4)
     np.testing.assert_allclose(rec[vis, 2:5], fr.conic_opacity[vis, :3], rtol=3e-5, atol=2e-6)   # B cancels to ~0
     np.testing.assert_allclose(rec[vis, 6:9], fr.rgb[vis], rtol=1e-5, atol=2e-6)
+    # last contributor per pixel: same GAUSSIAN as the oracle's (positions differ because of the culling)
     nc = _decode_n_contrib(v, lens, fr.W, fr.H)
     strict = fr.fragile_px == 0
-    assert (nc[strict] == fr.n_contrib[strict]).mean() > 0.9999
+    ys, xs = np.mgrid[0:fr.H, 0:fr.W]
+    tile = (ys // 16) * fr.Gx + xs // 16
+    same = 0
+    idx = np.nonzero(strict)
+    for y, x in zip(*idx):
+        t = tile[y, x]
+        g_dev = lists[t][nc[y, x] - 1] if nc[y, x] > 0 else -1
+        g_ora = fr.point_list[fr.ranges[t, 0] + fr.n_contrib[y, x] - 1] if fr.n_contrib[y, x] > 0 else -1
+        same += int(g_dev == g_ora)
+    assert same / idx[0].size > 0.9999
     np.testing.assert_allclose(np.abs(v["final_T"].cpu().numpy())[strict], fr.final_T[strict], rtol=1e-4, atol=1e-7)
 
 

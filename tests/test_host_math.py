@@ -113,3 +113,37 @@ def test_geom_backward_matches_oracle(hh, mode):
         # fp32 evaluation of a cancellation-prone chain: 1e-4 of the tensor's scale, 2e-3 relative per element
         err = np.abs(g - w)
         assert (err <= 1e-4 * scale + 2e-3 * np.abs(w)).all(), f"{n}: max err {err.max():.3e} scale {scale:.3e}"
+
+
+def test_tile_culling_is_conservative(hh):
+    """csrc/gsr_math.h tile_may_contribute(): whenever it says "no", the oracle (fp32 AND fp64) finds no pixel
+    of that tile that accepts the splat; and it does cull a useful share of the rectangle instances."""
+    scene, cam = S.make_scene(6000, 256, 192, 0, 91, scale_lo=0.004, scale_hi=0.12), S.make_camera(256, 192)
+    kw = raster_kwargs(scene, cam)
+    fr = oracle.rasterize(dtype=np.float32, **kw)
+    fr64 = oracle.rasterize(dtype=np.float64, **kw)
+    vis = np.nonzero(fr.radii > 0)[0]
+    gs, txs, tys = [], [], []
+    for g in vis:
+        x0, y0, x1, y1 = fr.rect[g]
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        gs.append(np.full(xx.size, g)); txs.append(xx.ravel()); tys.append(yy.ravel())
+    g = np.concatenate(gs); tx = np.concatenate(txs).astype(np.int32); ty = np.concatenate(tys).astype(np.int32)
+    co = fr.conic_opacity[g].astype(np.float32)
+    sx, sy = (np.ascontiguousarray(fr.xy[g, i], np.float32) for i in (0, 1))
+    A, B, Cc, op = (np.ascontiguousarray(co[:, i]) for i in range(4))
+    out = np.zeros(g.size, np.uint8)
+    hh.hh_tile_may_contribute(g.size, _p(sx), _p(sy), _p(A), _p(B), _p(Cc), _p(op), _p(tx), _p(ty), _p(out))
+    culled = np.nonzero(out == 0)[0]
+    assert 0.2 < culled.size / g.size < 0.9, culled.size / g.size
+    # brute force on the culled instances: max over the tile's pixels of alpha, both precisions
+    px = (tx[culled, None] * 16 + np.arange(16)[None, :])[:, None, :]          # [n,1,16]
+    py = (ty[culled, None] * 16 + np.arange(16)[None, :])[:, :, None]          # [n,16,1]
+    for frx in (fr, fr64):
+        co_ = frx.conic_opacity[g[culled]].astype(np.float64)
+        dx = frx.xy[g[culled], 0].astype(np.float64)[:, None, None] - px
+        dy = frx.xy[g[culled], 1].astype(np.float64)[:, None, None] - py
+        power = -0.5 * (co_[:, 0, None, None] * dx * dx + co_[:, 2, None, None] * dy * dy) - co_[:, 1, None, None] * dx * dy
+        alpha = np.minimum(0.99, co_[:, 3, None, None] * np.exp(np.minimum(power, 0)))
+        accept = (power <= 0) & (alpha >= (1 / 255) * (1 - 1e-3))
+        assert not accept.any(), f"{accept.any((1, 2)).sum()} culled instances have an accepting pixel"
