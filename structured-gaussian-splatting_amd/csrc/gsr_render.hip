@@ -41,6 +41,29 @@ __device__ __forceinline__ float dpp_add(float v)
     return v + __int_as_float(t);
 }
 
+// Nine independent wave sums in ONE asm block, step-major: v_add_f32_dpp v, v, v <ctrl> computes
+// v = dpp(v) + v (lanes whose DPP source does not exist are disabled and keep v, i.e. add 0).  The same
+// register's next step is nine instructions later, which covers the VALU-write -> DPP-read wait states; the
+// leading s_nop covers the instruction that produced the inputs.  Totals land in lane 63.
+#define GSR_DPP9(ctrl)                                                                                   \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %6, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
+    "v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void wave_sum9_to_lane63(float &a, float &b, float &c, float &d, float &e, float &f_, float &g,
+                                                    float &h, float &i)
+{
+    asm volatile("s_nop 1\n\t" GSR_DPP9("row_shr:1") GSR_DPP9("row_shr:2") GSR_DPP9("row_shr:4") GSR_DPP9("row_shr:8")
+                     GSR_DPP9("row_bcast:15") GSR_DPP9("row_bcast:31") "s_nop 1"
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f_), "+v"(g), "+v"(h), "+v"(i));
+}
+#undef GSR_DPP9
+
 // Sum over the 64 lanes; the total lands in lane 63 (other lanes hold partial sums).
 __device__ __forceinline__ float wave_sum_to_lane63(float v)
 {
@@ -48,8 +71,8 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     v = dpp_add<0x112, 0xf, 0xf>(v);   // row_shr:2
     v = dpp_add<0x114, 0xf, 0xf>(v);   // row_shr:4
     v = dpp_add<0x118, 0xf, 0xf>(v);   // row_shr:8   -> lane 15 of each row = row total
-    v = dpp_add<0x142, 0xa, 0xf>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc, 0xf>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+    v = dpp_add<0x142, 0xf, 0xf>(v);   // row_bcast:15: row r += lane 15 of row r-1 (row 0: no source -> +0)
+    v = dpp_add<0x143, 0xf, 0xf>(v);   // row_bcast:31: rows 2,3 += lane 31          -> lane 63 = total
     return v;
 }
 
@@ -180,7 +203,7 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
 // One launch for the whole frame: a tile's wave walks its chunks last to first, each chunk's range back to
 // front.  A pixel takes part in chunk c up to its own last contributor (all of the range for chunks before
 // the one that holds it, nothing after).
-__global__ __launch_bounds__(kWave) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
+__global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
                                                       const uint32_t *__restrict__ sorted_gid,
                                                       const uint32_t *__restrict__ sorted_slot,
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(kWave) void k_render_bwd(FrameK f, int n_tiles, int
             const int n = min(kWave, n_total - base);
             uint32_t slot = 0;
             if (lane < n) slot = sorted_slot[rng.x + base + lane];
-            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f, o4 = 0.f, o5 = 0.f, o6 = 0.f, o7 = 0.f, o8 = 0.f;
+            unsigned long long written = 0ull;                 // wave-uniform: bit j = splat j's row stored
             if (base < max_contrib) {
                 __syncthreads();
                 if (lane < n) {
@@ -296,23 +319,23 @@ __global__ __launch_bounds__(kWave) void k_render_bwd(FrameK f, int n_tiles, int
                         lalpha[k] = valid ? alpha : lalpha[k];
                     }
                     if (__ballot(any_valid) == 0ull) continue;               // nobody accepted this splat: row stays 0
-                    s0 = bcast_lane63(wave_sum_to_lane63(s0)) * half_w;
-                    s1 = bcast_lane63(wave_sum_to_lane63(s1)) * half_h;
-                    s2 = bcast_lane63(wave_sum_to_lane63(s2)) * -0.5f;
-                    s3 = bcast_lane63(wave_sum_to_lane63(s3)) * -0.5f;
-                    s4 = bcast_lane63(wave_sum_to_lane63(s4)) * -0.5f;
-                    s5 = bcast_lane63(wave_sum_to_lane63(s5));
-                    s6 = bcast_lane63(wave_sum_to_lane63(s6));
-                    s7 = bcast_lane63(wave_sum_to_lane63(s7));
-                    s8 = bcast_lane63(wave_sum_to_lane63(s8));
-                    if (lane == j) { o0 = s0; o1 = s1; o2 = s2; o3 = s3; o4 = s4; o5 = s5; o6 = s6; o7 = s7; o8 = s8; }
+                    wave_sum9_to_lane63(s0, s1, s2, s3, s4, s5, s6, s7, s8);
+                    // lane 63 holds the nine totals: it stores the splat's row itself (three 16-B stores)
+                    const uint32_t slot_j = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
+                    written |= 1ull << j;
+                    if (lane == kWave - 1) {
+                        float4 *row = grad_rows + 3 * (size_t)slot_j;
+                        row[0] = make_float4(s0 * half_w, s1 * half_h, s2 * -0.5f, s3 * -0.5f);
+                        row[1] = make_float4(s4 * -0.5f, s5, s6, s7);
+                        row[2] = make_float4(s8, 0.f, 0.f, 0.f);
+                    }
                 }
             }
-            if (lane < n) {
+            // rows of splats that were never reduced (past every pixel's last contributor, or accepted by nobody)
+            if (lane < n && !((written >> lane) & 1ull)) {
                 float4 *row = grad_rows + 3 * (size_t)slot;
-                row[0] = make_float4(o0, o1, o2, o3);
-                row[1] = make_float4(o4, o5, o6, o7);
-                row[2] = make_float4(o8, 0.f, 0.f, 0.f);
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                row[0] = z; row[1] = z; row[2] = z;
             }
         }
     }
