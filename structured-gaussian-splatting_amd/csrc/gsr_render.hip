@@ -360,7 +360,7 @@ int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, in
 // rows each; one thread per Gaussian left a tail of a few thousand threads walking them serially.
 // Only ranks of chunks that actually ran can own rows; every other Gaussian's gradient row is zero (memset).
 constexpr int kRedBlock = 256;
-constexpr int kRedGroup = 8;
+template <int kRedGroup>
 __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const uint32_t *__restrict__ order,
                                                            const uint32_t *__restrict__ cnt_open,
                                                            const uint32_t *__restrict__ row_begin,
@@ -394,17 +394,24 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const ui
     }
 }
 
-int launch_reduce_rows(const FrameK &f, int n_ranks, const GeomWS &gw, const BinningWS &bw, float *screen_grads, bool debug,
-                       hipStream_t s)
+int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
+                       float *screen_grads, bool debug, hipStream_t s)
 {
     if (f.P == 0) return GSR_OK;
     ProfileScope prof("reduce_rows", s);
     GSR_HIP_CHECK(hipMemsetAsync(screen_grads, 0, (size_t)f.P * kRowFloats * sizeof(float), s));
     if (n_ranks > 0) {
-        const long long threads = (long long)n_ranks * kRedGroup;
-        hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)((threads + kRedBlock - 1) / kRedBlock)), dim3(kRedBlock), 0, s, n_ranks,
-                           gw.order, gw.cnt_open, gw.row_begin, reinterpret_cast<const float4 *>(bw.grad_rows),
-                           reinterpret_cast<float4 *>(screen_grads));
+        // lanes per Gaussian: a whole wave when the processed Gaussians own many rows each (depth-complex scenes:
+        // a few thousand screen-filling splats), eight otherwise
+        const bool wide = rows_upper / (long long)n_ranks >= 48;
+        const long long threads = (long long)n_ranks * (wide ? 64 : 8);
+        const dim3 grid((unsigned)((threads + kRedBlock - 1) / kRedBlock));
+        if (wide)
+            hipLaunchKernelGGL(k_reduce_rows<64>, grid, dim3(kRedBlock), 0, s, n_ranks, gw.order, gw.cnt_open, gw.row_begin,
+                               reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads));
+        else
+            hipLaunchKernelGGL(k_reduce_rows<8>, grid, dim3(kRedBlock), 0, s, n_ranks, gw.order, gw.cnt_open, gw.row_begin,
+                               reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads));
     }
     GSR_LAUNCH_CHECK("reduce_rows", debug, s);
     return GSR_OK;
