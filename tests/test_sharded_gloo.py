@@ -41,6 +41,15 @@ class OracleBackend:
         out[:, :9] = torch.from_numpy(scr)
         return out.to(grad_color.dtype)
 
+    def binned_prefix(self, fr):
+        # the oracle bins everything: no usable prefix -> dense exchange (exercised), or a fake prefix in depth order
+        if not getattr(self, "use_prefix", False):
+            return None, fr.P
+        vis = np.nonzero(fr.radii > 0)[0]
+        order = vis[np.lexsort((vis, fr.depth[vis]))]
+        rest = np.setdiff1d(np.arange(fr.P), order)
+        return torch.from_numpy(np.concatenate([order, rest])), int(order.size)
+
     def backward_geom(self, fr, screen, needs, g0, g1):
         g = fr.backward_geom(screen[:, :9].double().numpy(), g0, g1)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(screen.dtype)
@@ -55,7 +64,7 @@ def _case():
     return scene, cam
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode, use_prefix):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -70,7 +79,9 @@ def _worker(rank, world, port, q):
                                            torch.tensor([0.1, 0.2, 0.3], dtype=torch.float32).double(), 1.0,
                                            cam.world_view_transform.double(), cam.full_proj_transform.double(), scene.sh_degree,
                                            cam.camera_center.double(), False, False)
-        sr = ShardedRenderer(dist, world, rank, backend=OracleBackend())
+        be = OracleBackend()
+        be.use_prefix = use_prefix
+        sr = ShardedRenderer(dist, world, rank, backend=be, backward_mode=mode)
         image, radii = sr.rasterize(rs, leaves["means3D"], means2D, leaves["opacities"], shs=leaves["shs"],
                                     scales=leaves["scales"], rotations=leaves["rotations"])
         gimg = S.make_grad_image(cam.image_width, cam.image_height, 5).double()
@@ -90,13 +101,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_equals_single(world):
+@pytest.mark.parametrize("world,mode,use_prefix", [(2, "allreduce_screen", False), (2, "allreduce_screen", True),
+                                                   (3, "allreduce_screen", True), (2, "reduce_scatter", False),
+                                                   (3, "reduce_scatter", False)])
+def test_sharded_equals_single(world, mode, use_prefix):
     import oracle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, use_prefix)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=240) for _ in range(world))
