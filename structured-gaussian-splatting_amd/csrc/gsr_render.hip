@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
     float fy[kStrips], T[kStrips], bgterm[kStrips], dpr[kStrips], dpg[kStrips], dpb[kStrips];
-    float ar[kStrips], ag[kStrips], ab[kStrips], lalpha[kStrips], lr[kStrips], lg[kStrips], lb[kStrips];
+    float ar[kStrips], ag[kStrips], ab[kStrips];               // colour behind the current splat, per pixel
     int c_last[kStrips], n_last[kStrips];
 #pragma unroll
     for (int k = 0; k < kStrips; ++k) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
         dpg[k] = inside ? dL_dpix[N + pix] : 0.f;
         dpb[k] = inside ? dL_dpix[2 * N + pix] : 0.f;
         bgterm[k] = -T[k] * (bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k]);   // -T_final * <bg, dL/dpix>
-        ar[k] = ag[k] = ab[k] = 0.f; lalpha[k] = 0.f; lr[k] = lg[k] = lb[k] = 0.f;
+        ar[k] = ag[k] = ab[k] = 0.f;
     }
     const float half_w = 0.5f * (float)f.W, half_h = 0.5f * (float)f.H;
 
@@ -291,32 +291,30 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
                         const float alpha = fminf((float)GSR_ALPHA_MAX, b.y * G);
                         const bool valid = (pos < limit[k]) && !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
                         any_valid = any_valid || valid;
-                        const float inv1ma = fast_rcp(1.f - alpha);
+                        // Rejected pixels run the same arithmetic with alpha = 0 and G = 0: T, the colour behind and
+                        // every partial sum then stay exactly unchanged, so only these two values need a select.
+                        const float ae = valid ? alpha : 0.f;
+                        const float Ge = valid ? G : 0.f;
+                        const float inv1ma = fast_rcp(1.f - ae);
                         const float Tn_ = T[k] * inv1ma;                      // T before this splat
-                        const float w = alpha * Tn_;                          // d colour / d rgb
-                        const float nar = lalpha[k] * lr[k] + (1.f - lalpha[k]) * ar[k];
-                        const float nag = lalpha[k] * lg[k] + (1.f - lalpha[k]) * ag[k];
-                        const float nab = lalpha[k] * lb[k] + (1.f - lalpha[k]) * ab[k];
-                        float dL_dalpha = (b.z - nar) * dpr[k] + (b.w - nag) * dpg[k] + (cb - nab) * dpb[k];
+                        const float w = ae * Tn_;                             // d colour / d rgb
+                        // colour behind this splat (A.9's accum_rec), updated as soon as the splat is processed:
+                        // B <- alpha c + (1 - alpha) B
+                        const float dr = b.z - ar[k], dg = b.w - ag[k], db = cb - ab[k];
+                        float dL_dalpha = dr * dpr[k] + dg * dpg[k] + db * dpb[k];
+                        ar[k] += ae * dr; ag[k] += ae * dg; ab[k] += ae * db;
                         dL_dalpha = dL_dalpha * Tn_ + bgterm[k] * inv1ma;
-                        const float dL_dG = b.y * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                        const float dG_ddely = -gdy * b.x - gdx * a.w;
-                        const float v = valid ? 1.f : 0.f;
-                        const float vG = v * dL_dG;
-                        s0 += vG * dG_ddelx;
-                        s1 += vG * dG_ddely;
-                        s2 += vG * gdx * dx;
-                        s3 += vG * gdx * dy;
-                        s4 += vG * gdy * dy;
-                        s5 += v * G * dL_dalpha;
-                        const float vw = v * w;
-                        s6 += vw * dpr[k]; s7 += vw * dpg[k]; s8 += vw * dpb[k];
-                        T[k] = valid ? Tn_ : T[k];
-                        ar[k] = valid ? nar : ar[k]; ag[k] = valid ? nag : ag[k]; ab[k] = valid ? nab : ab[k];
-                        lr[k] = valid ? b.z : lr[k]; lg[k] = valid ? b.w : lg[k]; lb[k] = valid ? cb : lb[k];
-                        lalpha[k] = valid ? alpha : lalpha[k];
+                        const float gdx = Ge * dx, gdy = Ge * dy;
+                        const float tG = b.y * dL_dalpha;                     // dL/dG (times G through gdx, gdy)
+                        const float tx = tG * gdx, ty = tG * gdy;
+                        s0 -= tx * a.z + ty * a.w;                            // dL/dG * dG/ddelx
+                        s1 -= ty * b.x + tx * a.w;
+                        s2 += tx * dx;
+                        s3 += tx * dy;
+                        s4 += ty * dy;
+                        s5 += Ge * dL_dalpha;
+                        s6 += w * dpr[k]; s7 += w * dpg[k]; s8 += w * dpb[k];
+                        T[k] = Tn_;
                     }
                     if (__ballot(any_valid) == 0ull) continue;               // nobody accepted this splat: row stays 0
                     wave_sum9_to_lane63(s0, s1, s2, s3, s4, s5, s6, s7, s8);

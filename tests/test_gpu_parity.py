@@ -310,11 +310,23 @@ def test_slab_renders_tile_the_image_and_gradients_sum():
     sfull = dgr.rasterize_backward_screen(fr, gimg)
     acc = torch.zeros_like(full)
     ssum = torch.zeros_like(sfull)
+    from diff_gaussian_rasterization import _native as N
+    from diff_gaussian_rasterization.sharded import NativeBackend
+    order_full = N.debug_views(fr.desc, fr.geom_ws, None, None, fr.plan)["depth_order"].clone()
     for rows in ((0, 5), (5, 6), (6, 12)):
         dgr.rasterize_forward(*args, tile_rows=rows, out_color=acc)
         _, r2, f2 = dgr.rasterize_forward(*args, tile_rows=rows)
         assert torch.equal(r2, radii)
-        ssum += dgr.rasterize_backward_screen(f2, gimg)
+        part = dgr.rasterize_backward_screen(f2, gimg)
+        ssum += part
+        # what the multi-GPU exchange relies on: the depth order does not depend on the slab, and a slab's
+        # non-zero gradient rows all belong to its binned depth prefix
+        order, n_prefix = NativeBackend().binned_prefix(f2)
+        assert torch.equal(order, order_full)
+        live = (part.abs().sum(1) > 0).nonzero().flatten()
+        in_prefix = torch.zeros(part.shape[0], dtype=torch.bool, device=DEV)
+        in_prefix[order[:n_prefix].long()] = True
+        assert bool(in_prefix[live].all())
     assert torch.equal(acc, full)
     scale = sfull.abs().max()
     assert (ssum - sfull).abs().max() <= 2e-6 * scale
