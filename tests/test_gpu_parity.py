@@ -60,10 +60,32 @@ def _run_gpu(kw, grad_img=None, debug=False):
     return color.detach().cpu().numpy(), radii.cpu().numpy(), grads
 
 
-def _check_forward(kw, fr64, color, radii):
-    np.testing.assert_array_equal(radii, fr64.radii)
-    err = np.abs(color.astype(np.float64) - fr64.color).max(0)
+def _check_forward(kw, fr64, color, radii, exact_radii=True):
     strict = fr64.fragile_px == 0
+    if exact_radii:
+        np.testing.assert_array_equal(radii, fr64.radii)
+    else:
+        # at 1e6 Gaussians a handful sit on an integer boundary of ceil(3 sqrt(lambda)): binary32 vs binary64 may
+        # round the radius differently by one; the tiles such a Gaussian touches are excluded from the strict check
+        bad = np.nonzero(radii != fr64.radii)[0]
+        assert bad.size <= 1e-5 * radii.size and np.all(np.abs(radii[bad] - fr64.radii[bad]) <= 1), bad.size
+        strict = strict.copy()
+
+        def rect(g, r):                      # A.5 for Gaussian g with radius r
+            x, y = fr64.xy[g]
+            lo = lambda v, G: int(min(G, max(0, int((v - r) / 16))))
+            hi = lambda v, G: int(min(G, max(0, int((v + r + 15) / 16))))
+            return lo(x, fr64.Gx), lo(y, fr64.Gy), hi(x, fr64.Gx), hi(y, fr64.Gy)
+        for g in bad:                        # only tiles inside one rectangle and not the other can differ
+            ra, rb = rect(g, radii[g]), rect(g, fr64.radii[g])
+            if ra != rb:
+                x0, y0, x1, y1 = min(ra[0], rb[0]), min(ra[1], rb[1]), max(ra[2], rb[2]), max(ra[3], rb[3])
+                inner = (max(ra[0], rb[0]), max(ra[1], rb[1]), min(ra[2], rb[2]), min(ra[3], rb[3]))
+                m = np.zeros_like(strict)
+                m[y0 * 16:y1 * 16, x0 * 16:x1 * 16] = True
+                m[inner[1] * 16:inner[3] * 16, inner[0] * 16:inner[2] * 16] = False
+                strict &= ~m
+    err = np.abs(color.astype(np.float64) - fr64.color).max(0)
     assert strict.mean() > 0.97, f"too many fragile pixels: {1 - strict.mean():.4f}"
     assert err[strict].max() <= 1e-5, f"pixel error {err[strict].max():.3e} on non-fragile pixels"
     if (~strict).any():        # one splat more or less: <= alpha_min * |colour| (+ downstream T change)
@@ -450,3 +472,30 @@ def test_fused_loss_matches_reference_golden():
     a2 = a.detach().clone().requires_grad_(True)
     (loss_utils.training_loss_torch(a2, b) * 3.0).backward()
     assert (a.grad - a2.grad).abs().max() <= 2e-4 * a2.grad.abs().max()
+
+
+def test_cfg3_full_size_vs_oracle():
+    """BASELINE.json configs[2] scene at full size (1e6 Gaussians, 1920x1080, SH 3): forward and backward
+    against the fp64 oracle.  This frame exercises everything the progressive pipeline adds: 2 of 3 depth
+    chunks run, 97 % of the reference's 43.8 M instances are never binned (closed tiles + tile culling)."""
+    scene, cam = S.make_config("cfg3")
+    kw = raster_kwargs(scene, cam)
+    fr64 = oracle.rasterize(dtype=np.float64, parallel=True, **kw)
+    gimg = S.make_grad_image(1920, 1080, 3).numpy()
+    color, radii, grads = _run_gpu(kw, gimg)
+    _check_forward(kw, fr64, color, radii, exact_radii=False)
+    want = fr64.backward(gimg.astype(np.float64), parallel=True)
+    bad = radii != fr64.radii
+    fr64.fragile_g[:] = fr64.fragile_g | bad.astype(np.uint8)       # their own gradients are not comparable
+    _check_grads(fr64, want, grads, ["means3D", "means2D", "opacities", "shs", "scales", "rotations"])
+
+
+def test_debug_flag_synchronises_and_matches():
+    """`debug=True` (README.md:147-150 semantics: check after every kernel) gives the same result."""
+    kw = _fixture_kwargs(dict(P=2048, W=128, H=128, D=3, seed=105))
+    gimg = S.make_grad_image(128, 128, 1).numpy()
+    c0, r0, g0 = _run_gpu(kw, gimg, debug=False)
+    c1, r1, g1 = _run_gpu(kw, gimg, debug=True)
+    assert np.array_equal(c0, c1) and np.array_equal(r0, r1)
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
