@@ -59,8 +59,10 @@ typedef struct gsr_frame_desc {
  * transmittance cut-off (A.8) takes no further instances.  Pixels are identical to binning everything. */
 #define GSR_MAX_CHUNKS 8
 typedef struct gsr_frame_plan {
-    int64_t num_rendered;                         /* R: sum of (slab-clipped) tiles touched = the reference's
-                                                     num_rendered; upper bound of the instances emitted      */
+    int64_t num_rendered;                         /* R: sum over Gaussians of the tiles of their binning
+                                                     rectangle (the reference's rectangle clipped to the slab and to
+                                                     the alpha >= 1/255 bounding box): upper bound of the instances
+                                                     emitted; <= the reference's num_rendered                */
     int32_t num_visible;                          /* V: Gaussians with radius > 0                           */
     int32_t num_chunks;                           /* depth chunks planned (1..GSR_MAX_CHUNKS)               */
     int32_t chunk_rank_begin[GSR_MAX_CHUNKS + 1]; /* chunk c = depth ranks [begin[c], begin[c+1])           */
@@ -134,7 +136,7 @@ int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, c
 /* Introspection for tests / profiling: copies of intermediate device arrays' ADDRESSES inside the
  * workspaces (no data is copied).  Any out-pointer may be NULL. */
 typedef struct gsr_debug_views {
-    const float *splat_records;   /* [P,12]: x, y, conicA, conicB, conicC, opacity, r, g, b, depth, radius, 0 */
+    const float *splat_records;   /* [P,12]: x, y, conicA, conicB, conicC, opacity, r, g, b, depth, packed tile rect (2) */
     const uint32_t *tiles_touched; /* [P]  by Gaussian */
     const uint32_t *depth_order;   /* [P]  depth rank -> Gaussian (invisible ones last)                   */
     const uint32_t *point_offsets; /* [P]  inclusive scan of tiles touched, in depth order               */

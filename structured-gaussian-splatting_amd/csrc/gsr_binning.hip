@@ -228,8 +228,7 @@ __global__ __launch_bounds__(kBinBlock) void k_count_open(FrameK f, int r0, int 
         if (!nothing_open) {
             const uint32_t g = order[r];
             const float4 a = records[3 * (size_t)g], b = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
-            TileRect t = tile_rect(a.x, a.y, cc.z, f);
-            slab_clip(t, f);
+            const TileRect t = unpack_rect(cc.z, cc.w);
             const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0);
             for (int i0 = 0; i0 < total; i0 += kWave) {
                 uint32_t tile;
@@ -265,8 +264,7 @@ __global__ __launch_bounds__(kBinBlock) void k_emit(FrameK f, int c, int r0, int
         if (cnt == 0) continue;
         const uint32_t g = order[r];
         const float4 a = records[3 * (size_t)g], b = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
-        TileRect t = tile_rect(a.x, a.y, cc.z, f);
-        slab_clip(t, f);
+        const TileRect t = unpack_rect(cc.z, cc.w);
         const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0);
         uint32_t emitted = 0;
         for (int i0 = 0; i0 < total; i0 += kWave) {

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
     clamped[i] = (uint8_t)o.clamped;
     records[3 * (size_t)i + 0] = make_float4(o.s.x, o.s.y, o.s.cA, o.s.cB);
     records[3 * (size_t)i + 1] = make_float4(o.s.cC, o.s.op, o.s.r, o.s.g);
-    records[3 * (size_t)i + 2] = make_float4(o.s.b, o.s.depth, o.s.radius, 0.f);
+    records[3 * (size_t)i + 2] = make_float4(o.s.b, o.s.depth, o.s.rect_x, o.s.rect_y);
     // depth-sort key: binary32 pattern of the (positive) view depth; invisible Gaussians sort last.  Visibility
     // is that of the FULL image (radius > 0), not of this rank's slab, so that the depth order is identical on
     // every rank of a sharded render (the multi-GPU gradient exchange indexes by depth rank).

@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/gsr_constants.h"
 
@@ -29,7 +30,8 @@ struct FrameK {            // kernel-side scalars derived from gsr_frame_desc
 struct Splat {             // 48-byte record consumed by the render kernels (3 x float4)
     float x, y, cA, cB;    // pixel-space mean, conic A, B
     float cC, op, r, g;    // conic C, opacity, colour r g
-    float b, depth, radius, pad1;   // radius: integer-valued 3-sigma radius in pixels (A.4), for the tile rect
+    float b, depth, rect_x, rect_y; // rect_x / rect_y: bit patterns of (x0 | x1 << 16), (y0 | y1 << 16): the tile
+                                    // rectangle the binning walks (tight_rect below), slab-clipped
 };
 
 struct TileRect { int x0, y0, x1, y1; };
@@ -86,6 +88,48 @@ GSR_HD void slab_clip(TileRect &r, const FrameK &f)
     if (r.y0 < f.ty0) r.y0 = f.ty0;
     if (r.y1 > f.ty1) r.y1 = f.ty1;
     if (r.y1 < r.y0) r.y1 = r.y0;
+}
+
+// ---- the rectangle the binning actually walks: the reference's A.5 rectangle (a pixel outside it never sees
+// the splat, whatever its alpha) INTERSECTED with the bounding box of the region where alpha can reach 1/255:
+// |dx| <= sqrt(2 L cov_xx), |dy| <= sqrt(2 L cov_yy), L = ln(255 opacity), cov = 2D covariance incl. dilation.
+// Outside that box op * exp(power) < 1/255 for every pixel, so no tile there can take the splat: exact.
+// 2 % + 0.5 px of margin covers the blend kernels' fp32 arithmetic.  L <= 0: the splat is never accepted.
+GSR_HD TileRect tight_rect(const TileRect &ref, float px, float py, float cov_xx, float cov_yy, float opacity)
+{
+    TileRect r = ref;
+    const float L = logf(255.f * opacity);
+    if (!(L > 0.f)) { r.x1 = r.x0; r.y1 = r.y0; return r; }
+    const float xe = 1.02f * sqrtf(2.f * L * cov_xx) + 0.5f, ye = 1.02f * sqrtf(2.f * L * cov_yy) + 0.5f;
+    const float inv = 1.f / (float)GSR_TILE;
+    const int x0 = (int)floorf((px - xe) * inv), x1 = (int)floorf((px + xe) * inv) + 1;
+    const int y0 = (int)floorf((py - ye) * inv), y1 = (int)floorf((py + ye) * inv) + 1;
+    if (x0 > r.x0) r.x0 = x0;
+    if (x1 < r.x1) r.x1 = x1;
+    if (y0 > r.y0) r.y0 = y0;
+    if (y1 < r.y1) r.y1 = y1;
+    if (r.x1 < r.x0) r.x1 = r.x0;
+    if (r.y1 < r.y0) r.y1 = r.y0;
+    return r;
+}
+
+GSR_HD float pack_u16x2(int lo, int hi)
+{
+    const uint32_t u = ((uint32_t)lo & 0xFFFFu) | (((uint32_t)hi & 0xFFFFu) << 16);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+GSR_HD TileRect unpack_rect(float rx, float ry)
+{
+    uint32_t ux, uy;
+    memcpy(&ux, &rx, 4);
+    memcpy(&uy, &ry, 4);
+    TileRect r;
+    r.x0 = (int)(ux & 0xFFFFu); r.x1 = (int)(ux >> 16);
+    r.y0 = (int)(uy & 0xFFFFu); r.y1 = (int)(uy >> 16);
+    return r;
 }
 
 // ---- A.3: rotation from quaternion (r,x,y,z) used as given; utils/general_utils.py:90-98.
@@ -271,9 +315,11 @@ GSR_HD void preprocess_one(const FrameK &f, const float *V, const float *PV, con
     o.s.op = opacity;
     o.s.r = rgb[0]; o.s.g = rgb[1]; o.s.b = rgb[2];
     o.s.depth = pv[2];
-    o.s.radius = my_radius;
-    slab_clip(r, f);
-    o.tiles = (unsigned)((r.x1 - r.x0) * (r.y1 - r.y0));
+    TileRect t = tight_rect(r, px, py, e.a, e.c, opacity);
+    slab_clip(t, f);
+    o.s.rect_x = pack_u16x2(t.x0, t.x1);
+    o.s.rect_y = pack_u16x2(t.y0, t.y1);
+    o.tiles = (unsigned)((t.x1 - t.x0) * (t.y1 - t.y0));
 }
 
 struct GeomGrad {

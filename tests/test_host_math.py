@@ -61,7 +61,14 @@ def test_preprocess_matches_oracle(hh, mode, D):
     fr = oracle.rasterize(dtype=np.float32, **kw)
     got = _run(hh, kw)
     np.testing.assert_array_equal(got["radii"], fr.radii)
-    np.testing.assert_array_equal(got["tiles"], fr.tiles_touched)
+    # the binning rectangle is the reference's A.5 rectangle clipped to the alpha >= 1/255 bounding box
+    assert np.all(got["tiles"] <= fr.tiles_touched) and got["tiles"].sum() < fr.tiles_touched.sum()
+    rx = got["rec"][:, 10].copy().view(np.uint32); ry = got["rec"][:, 11].copy().view(np.uint32)
+    x0, x1, y0, y1 = rx & 0xFFFF, rx >> 16, ry & 0xFFFF, ry >> 16
+    v = fr.radii > 0
+    assert np.all(x0[v] >= fr.rect[v, 0]) and np.all(x1[v] <= np.maximum(fr.rect[v, 2], x0[v]))
+    assert np.all(y0[v] >= fr.rect[v, 1]) and np.all(y1[v] <= np.maximum(fr.rect[v, 3], y0[v]))
+    np.testing.assert_array_equal(((x1 - x0) * (y1 - y0))[v], got["tiles"][v])
     vis = fr.radii > 0
     assert vis.sum() > 1000
     rec = got["rec"][vis]
@@ -75,7 +82,7 @@ def test_preprocess_matches_oracle(hh, mode, D):
     # slab clipping only changes the tile count
     slab = _run(hh, kw, slab=(2, 5))
     frs = oracle.rasterize(dtype=np.float32, tile_rows=(2, 5), **kw)
-    np.testing.assert_array_equal(slab["tiles"], frs.tiles_touched)
+    assert np.all(slab["tiles"] <= frs.tiles_touched) and np.all(slab["tiles"] <= got["tiles"])
     np.testing.assert_array_equal(slab["radii"], fr.radii)
 
 
@@ -134,6 +141,12 @@ def test_tile_culling_is_conservative(hh):
     A, B, Cc, op = (np.ascontiguousarray(co[:, i]) for i in range(4))
     out = np.zeros(g.size, np.uint8)
     hh.hh_tile_may_contribute(g.size, _p(sx), _p(sy), _p(A), _p(B), _p(Cc), _p(op), _p(tx), _p(ty), _p(out))
+    # the preprocess's tight rectangle removes instances too: those count as culled as well
+    got = _run(hh, kw)
+    rx = got["rec"][:, 10].copy().view(np.uint32); ry = got["rec"][:, 11].copy().view(np.uint32)
+    inside = (tx >= (rx & 0xFFFF)[g]) & (tx < (rx >> 16)[g]) & (ty >= (ry & 0xFFFF)[g]) & (ty < (ry >> 16)[g])
+    assert 0.05 < (~inside).mean() < 0.9
+    out[~inside] = 0
     culled = np.nonzero(out == 0)[0]
     assert 0.2 < culled.size / g.size < 0.9, culled.size / g.size
     # brute force on the culled instances: max over the tile's pixels of alpha, both precisions
