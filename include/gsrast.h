@@ -162,6 +162,13 @@ int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, f
                               const float *image, const float *target, const void *workspace, float *grad_image,
                               void *stream);
 
+/* Test hook for the hand-written radix sort (csrc/gsr_sort.hip): stable sort of n (key, value) u32 pairs on
+ * key bits [0, end_bit).  keys0/vals0 hold the input; *result_buffer says which pair of buffers holds the
+ * output.  count_on_device != 0 reads n from a device word (as the progressive binning does). */
+int gsr_debug_sort_temp_bytes(size_t *bytes);
+int gsr_debug_sort_pairs(uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1, int64_t n, int32_t end_bit,
+                         int32_t count_on_device, void *temp, int32_t *result_buffer, void *stream);
+
 /* Per-kernel device timing (hipEvent pairs recorded on the caller's stream around every kernel this
  * library launches, from any thread).  Off by default; the only process-wide state of the library,
  * mutex-protected, meant for benchmarks (one frame in flight).  gsr_profile_enable(1) resets the

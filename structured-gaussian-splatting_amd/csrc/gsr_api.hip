@@ -277,6 +277,33 @@ int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, c
     return launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
 }
 
+int gsr_debug_sort_temp_bytes(size_t *bytes)
+{
+    if (!bytes) return GSR_ERR_INVALID_ARGUMENT;
+    *bytes = radix_temp_bytes() + 256;
+    return GSR_OK;
+}
+
+int gsr_debug_sort_pairs(uint32_t *keys0, uint32_t *keys1, uint32_t *vals0, uint32_t *vals1, int64_t n, int32_t end_bit,
+                         int32_t count_on_device, void *temp, int32_t *result_buffer, void *stream)
+{
+    if (!keys0 || !keys1 || !vals0 || !vals1 || !temp || !result_buffer || n < 0 || n > 0xFFFFFFFFll || end_bit < 1 || end_bit > 32) {
+        set_error("gsr_debug_sort_pairs: bad argument");
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *keys[2] = {keys0, keys1}, *vals[2] = {vals0, vals1};
+    uint32_t *n_dev = reinterpret_cast<uint32_t *>((char *)temp + radix_temp_bytes());
+    const uint32_t n32 = (uint32_t)n;
+    if (count_on_device) GSR_HIP_CHECK(hipMemcpyAsync(n_dev, &n32, 4, hipMemcpyHostToDevice, s));
+    int result = 0;
+    int rc = launch_radix_sort<uint32_t>(keys, vals, count_on_device ? n_dev : nullptr, n32, (uint64_t)n, nullptr, 0, end_bit, temp,
+                                         &result, "debug_sort", false, s);
+    *result_buffer = result;
+    if (count_on_device) GSR_HIP_CHECK(hipStreamSynchronize(s));     // n32 lives on this stack frame
+    return rc;
+}
+
 int gsr_profile_enable(int enable)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -119,10 +119,10 @@ constexpr int kRadixBins = 256;
 constexpr int kRadixRounds = 4;                                  // 64-key rounds per wave per sub-tile
 constexpr int kRadixSubTile = kRadixBlock * kRadixRounds;        // 1024 keys
 
-__device__ __forceinline__ void block_range(uint32_t n, int nblocks, uint32_t &lo, uint32_t &hi)
+__device__ __forceinline__ void block_range(uint32_t n, int nblocks, uint32_t subtile, uint32_t &lo, uint32_t &hi)
 {
     uint32_t per = (n + nblocks - 1) / nblocks;
-    per = (per + kRadixSubTile - 1) / kRadixSubTile * kRadixSubTile;
+    per = (per + subtile - 1) / subtile * subtile;
     const uint64_t l = (uint64_t)blockIdx.x * per, h = l + per;
     lo = l < n ? (uint32_t)l : n;
     hi = h < n ? (uint32_t)h : n;
@@ -131,7 +131,7 @@ __device__ __forceinline__ void block_range(uint32_t n, int nblocks, uint32_t &l
 template <typename K>
 __global__ __launch_bounds__(kRadixBlock) void k_radix_hist(const K *__restrict__ keys, const uint32_t *__restrict__ n_ptr,
                                                             uint32_t n_host, const uint32_t *__restrict__ base_ptr, int shift,
-                                                            uint32_t *__restrict__ table)
+                                                            uint32_t subtile, uint32_t *__restrict__ table)
 {
     __shared__ uint32_t hist[kRadixBins];
     hist[threadIdx.x] = 0;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_hist(const K *__restrict_
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     if (base_ptr) keys += *base_ptr;
     uint32_t lo, hi;
-    block_range(n, gridDim.x, lo, hi);
+    block_range(n, gridDim.x, subtile, lo, hi);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kRadixBlock) {
         const uint32_t d = (uint32_t)(keys[i] >> shift) & 255u;
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
     for (int i = 0; i < kRadixBlock / kWave; ++i) wave_cnt[i][threadIdx.x] = 0;
     const uint32_t n = n_ptr ? *n_ptr : n_host;
     uint32_t lo, hi;
-    block_range(n, gridDim.x, lo, hi);
+    block_range(n, gridDim.x, kRadixSubTile, lo, hi);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     __syncthreads();
     for (uint32_t tile = lo; tile < hi; tile += kRadixSubTile) {
@@ -252,6 +252,100 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
     }
 }
 
+// ---- large-n scatter: same stable ranking, but the sub-tile (4096 keys) is first written to LDS in sorted
+// order and then streamed out, so that consecutive threads store consecutive keys of a digit's run (~16 keys =
+// 64 B per run and sub-tile) instead of 64 unrelated dwords per wave-instruction.  The first tile-sort pass sees
+// keys whose low byte walks through all 256 values (consecutive tiles of a rectangle): without the reorder
+// every store instruction touches 64 different cache lines.
+constexpr int kBigRounds = 16;
+constexpr int kBigSubTile = kRadixBlock * kBigRounds;            // 4096 keys
+template <typename K>
+__global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                                   K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                                   const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                                   const uint32_t *__restrict__ base_ptr, int shift,
+                                                                   const uint32_t *__restrict__ table,
+                                                                   const uint32_t *__restrict__ totals)
+{
+    if (base_ptr) {
+        const uint32_t bo = *base_ptr;
+        keys_in += bo; vals_in += bo; keys_out += bo; vals_out += bo;
+    }
+    __shared__ uint32_t base[kRadixBins];                          // next global position per digit for this block
+    __shared__ uint32_t delta[kRadixBins];                         // global position minus position in the sorted sub-tile
+    __shared__ volatile uint32_t wave_cnt[kRadixBlock / kWave][kRadixBins];
+    __shared__ uint32_t offs[kRadixBlock / kWave][kRadixBins];
+    __shared__ uint32_t sh_wave[kRadixBlock / kWave];
+    __shared__ K sk[kBigSubTile];
+    __shared__ uint32_t sv[kBigSubTile];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        const uint32_t tot = totals[threadIdx.x];
+        uint32_t all;
+        const uint32_t digit_excl = block_incl_scan(tot, sh_wave, &all) - tot;
+        base[threadIdx.x] = digit_excl + table[threadIdx.x * gridDim.x + blockIdx.x];
+    }
+#pragma unroll
+    for (int i = 0; i < kRadixBlock / kWave; ++i) wave_cnt[i][threadIdx.x] = 0;
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    uint32_t lo, hi;
+    block_range(n, gridDim.x, kBigSubTile, lo, hi);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    __syncthreads();
+    for (uint32_t tile = lo; tile < hi; tile += kBigSubTile) {
+        K key[kBigRounds];
+        uint32_t local[kBigRounds];
+#pragma unroll
+        for (int r = 0; r < kBigRounds; ++r) {
+            const uint32_t idx = tile + w * (kWave * kBigRounds) + r * kWave + lane;
+            const bool valid = idx < hi;
+            key[r] = valid ? keys_in[idx] : (K)0;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long m = __ballot((d >> bit) & 1u);
+                peers &= ((d >> bit) & 1u) ? m : ~m;
+            }
+            const uint32_t old = wave_cnt[w][d];
+            local[r] = old + (uint32_t)__popcll(peers & lt_mask);
+            if (valid && (peers & lt_mask) == 0ull) wave_cnt[w][d] = old + (uint32_t)__popcll(peers);
+        }
+        __syncthreads();
+        {                                                          // thread d: digit d of this sub-tile
+            uint32_t c[kRadixBlock / kWave], tot = 0;
+#pragma unroll
+            for (int i = 0; i < kRadixBlock / kWave; ++i) { c[i] = wave_cnt[i][threadIdx.x]; tot += c[i]; wave_cnt[i][threadIdx.x] = 0; }
+            uint32_t all;
+            uint32_t run = block_incl_scan(tot, sh_wave, &all) - tot;   // start of digit d inside the sorted sub-tile
+            delta[threadIdx.x] = base[threadIdx.x] - run;
+            base[threadIdx.x] += tot;
+#pragma unroll
+            for (int i = 0; i < kRadixBlock / kWave; ++i) { offs[i][threadIdx.x] = run; run += c[i]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kBigRounds; ++r) {
+            const uint32_t idx = tile + w * (kWave * kBigRounds) + r * kWave + lane;
+            if (idx < hi) {
+                const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+                const uint32_t p = offs[w][d] + local[r];
+                sk[p] = key[r];
+                sv[p] = vals_in[idx];
+            }
+        }
+        __syncthreads();
+        const uint32_t count = min((uint32_t)kBigSubTile, hi - tile);
+        for (uint32_t p = threadIdx.x; p < count; p += kRadixBlock) {
+            const K kk = sk[p];
+            const uint32_t dst = delta[(uint32_t)(kk >> shift) & 255u] + p;
+            keys_out[dst] = kk;
+            vals_out[dst] = sv[p];
+        }
+        __syncthreads();
+    }
+}
+
 int radix_blocks(uint64_t n_max)
 {
     uint64_t b = (n_max + 2047) / 2048;          // ~2 sub-tiles per block: enough blocks to fill 256 CUs early
@@ -272,15 +366,23 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
     *result = 0;
     if (n_max == 0 || end_bit <= begin_bit) return GSR_OK;
     ProfileScope prof(name, s);
-    const int B = radix_blocks(n_max);
+    const bool big = n_max >= (4ull << 20);          // large sorts: LDS-reordering scatter on 4096-key sub-tiles
+    int B = radix_blocks(n_max);
+    if (big) { uint64_t b = (n_max + 2 * kBigSubTile - 1) / (2 * kBigSubTile); B = (int)(b > kRadixMaxBlocks ? kRadixMaxBlocks : b); }
+    const uint32_t subtile = big ? kBigSubTile : kRadixSubTile;
     uint32_t *table = (uint32_t *)temp;
     uint32_t *totals = (uint32_t *)((char *)temp + align_up((size_t)kRadixBins * kRadixMaxBlocks * 4));
     int cur = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], n_ptr, n_host, base_ptr, shift, table);
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], n_ptr, n_host, base_ptr, shift, subtile,
+                           table);
         hipLaunchKernelGGL(k_radix_scan, dim3(kRadixBins), dim3(kRadixBlock), 0, s, table, B, totals);
-        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
-                           vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, table, totals);
+        if (big)
+            hipLaunchKernelGGL(k_radix_scatter_big<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, table, totals);
+        else
+            hipLaunchKernelGGL(k_radix_scatter<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, table, totals);
         cur ^= 1;
     }
     *result = cur;

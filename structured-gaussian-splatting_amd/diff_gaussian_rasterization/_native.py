@@ -59,7 +59,8 @@ class DebugViews(C.Structure):
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
            "gsr_forward_render", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
-           "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward")
+           "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward",
+           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs")
 
 _lib = None
 
@@ -217,3 +218,20 @@ def loss_backward(image, target, lam, upstream, workspace, grad_image):
     _check(load().gsr_loss_l1_ssim_backward(C.c_int32(Cn), C.c_int32(H), C.c_int32(W), C.c_float(lam), _ptr(upstream),
                                             _ptr(image), _ptr(target), _ptr(workspace), _ptr(grad_image),
                                             _stream(image.device)), "gsr_loss_l1_ssim_backward")
+
+
+def debug_sort_pairs(keys: torch.Tensor, vals: torch.Tensor, end_bit: int, count_on_device: bool = False):
+    """Stable radix sort of (int32-viewed-as-u32 key, value) pairs through the library's own sort (test hook)."""
+    n = keys.numel()
+    k = [keys.contiguous().clone(), torch.empty_like(keys)]
+    v = [vals.contiguous().clone(), torch.empty_like(vals)]
+    b = C.c_size_t(0)
+    _check(load().gsr_debug_sort_temp_bytes(C.byref(b)), "gsr_debug_sort_temp_bytes")
+    temp = torch.empty(b.value, dtype=torch.uint8, device=keys.device)
+    res = C.c_int32(0)
+    with torch.cuda.device(keys.device):
+        _check(load().gsr_debug_sort_pairs(_ptr(k[0]) or C.c_void_p(temp.data_ptr()), _ptr(k[1]) or C.c_void_p(temp.data_ptr()),
+                                           _ptr(v[0]) or C.c_void_p(temp.data_ptr()), _ptr(v[1]) or C.c_void_p(temp.data_ptr()),
+                                           C.c_int64(n), C.c_int32(end_bit), C.c_int32(int(count_on_device)), _ptr(temp),
+                                           C.byref(res), _stream(keys.device)), "gsr_debug_sort_pairs")
+    return k[res.value], v[res.value]

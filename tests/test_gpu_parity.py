@@ -500,3 +500,22 @@ def test_debug_flag_synchronises_and_matches():
     assert np.array_equal(c0, c1) and np.array_equal(r0, r1)
     for k in g0:
         assert np.array_equal(g0[k], g1[k]), k
+
+
+@pytest.mark.parametrize("n,end_bit,dev_count", [(0, 8, False), (1, 32, False), (1000, 13, True), (70_000, 32, False),
+                                                 (1_300_000, 15, True), (5_000_000, 13, True), (9_000_001, 32, False)])
+def test_radix_sort_is_stable_and_exact(n, end_bit, dev_count):
+    """csrc/gsr_sort.hip against torch.sort(stable=True): every size class (small scatter, LDS-reordering
+    scatter >= 4 M), host- and device-side counts, narrow (tile id) and full-width (depth) keys."""
+    from diff_gaussian_rasterization import _native as N
+    g = torch.Generator(device="cpu").manual_seed(n + end_bit)
+    hi = (1 << end_bit) - 1 if end_bit < 31 else (1 << 31) - 1
+    keys = torch.randint(0, hi + 1, (n,), generator=g, dtype=torch.int64).to(torch.int32).to(DEV)
+    if n > 10:                        # long runs of equal keys: stability matters
+        keys[: n // 3] = keys[0]
+    vals = torch.arange(n, dtype=torch.int32, device=DEV)
+    ks, vs = N.debug_sort_pairs(keys, vals, end_bit, dev_count)
+    torch.cuda.synchronize()
+    want_k, order = torch.sort(keys.long(), stable=True)
+    assert torch.equal(ks.long(), want_k)
+    assert torch.equal(vs.long(), order)
