@@ -162,6 +162,12 @@ int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, f
                               const float *image, const float *target, const void *workspace, float *grad_image,
                               void *stream);
 
+/* ---- `simple_knn._C.distCUDA2` (scene/gaussian_model.py:144-145): mean of the squared
+ * distances from each point to its 3 nearest other points (exact), used once to initialise the scales.
+ * xyz[P,3] -> mean_dist2[P]. */
+int gsr_dist2_workspace_size(int32_t P, size_t *bytes);
+int gsr_dist2_knn3(int32_t P, const float *xyz, float *mean_dist2, void *workspace, void *stream);
+
 /* Test hook for the hand-written radix sort (csrc/gsr_sort.hip): stable sort of n (key, value) u32 pairs on
  * key bits [0, end_bit).  keys0/vals0 hold the input; *result_buffer says which pair of buffers holds the
  * output.  count_on_device != 0 reads n from a device word (as the progressive binning does). */

@@ -60,7 +60,7 @@ class DebugViews(C.Structure):
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
            "gsr_forward_render", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward",
-           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs")
+           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3")
 
 _lib = None
 
@@ -235,3 +235,18 @@ def debug_sort_pairs(keys: torch.Tensor, vals: torch.Tensor, end_bit: int, count
                                            C.c_int64(n), C.c_int32(end_bit), C.c_int32(int(count_on_device)), _ptr(temp),
                                            C.byref(res), _stream(keys.device)), "gsr_debug_sort_pairs")
     return k[res.value], v[res.value]
+
+
+def dist2_knn3(xyz: torch.Tensor) -> torch.Tensor:
+    """Mean squared distance to the 3 nearest other points (gsr_dist2_knn3)."""
+    P = int(xyz.shape[0])
+    pts = xyz.detach().float().contiguous()
+    out = torch.zeros(P, dtype=torch.float32, device=pts.device)
+    if P == 0:
+        return out
+    b = C.c_size_t(0)
+    _check(load().gsr_dist2_workspace_size(C.c_int32(P), C.byref(b)), "gsr_dist2_workspace_size")
+    ws = torch.empty(b.value, dtype=torch.uint8, device=pts.device)
+    with torch.cuda.device(pts.device):
+        _check(load().gsr_dist2_knn3(C.c_int32(P), _ptr(pts), _ptr(out), _ptr(ws), _stream(pts.device)), "gsr_dist2_knn3")
+    return out

@@ -519,3 +519,25 @@ def test_radix_sort_is_stable_and_exact(n, end_bit, dev_count):
     want_k, order = torch.sort(keys.long(), stable=True)
     assert torch.equal(ks.long(), want_k)
     assert torch.equal(vs.long(), order)
+
+
+@pytest.mark.parametrize("P", [1, 2, 3, 5, 777, 20_000, 300_000])
+def test_dist2_knn3_matches_brute_force(P):
+    """csrc/gsr_knn.hip (the reference's simple_knn.distCUDA2) against the oracle's brute force
+    (up to 20k points) and against a chunked torch.cdist top-k beyond that."""
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(P)
+    pts = torch.randn(P, 3, generator=g) * torch.tensor([1.0, 0.3, 2.0])
+    if P >= 777:
+        pts[:50] = pts[50:100]                  # exact duplicates -> zero distances
+    got = distCUDA2(pts.to(DEV)).cpu().numpy()
+    if P <= 20_000:
+        want = oracle.dist2_knn3(pts.numpy())
+    else:
+        want = np.zeros(P, np.float32)
+        pd = pts.double().to(DEV)
+        for i in range(0, P, 4096):
+            d = torch.cdist(pd[i:i + 4096], pd).pow(2)
+            d[torch.arange(d.shape[0]), torch.arange(i, i + d.shape[0])] = float("inf")
+            want[i:i + 4096] = d.topk(3, largest=False).values.sum(1).div(3).float().cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-9)
