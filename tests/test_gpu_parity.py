@@ -12,6 +12,7 @@ against a bound of one skipped/added splat instead of 1e-5, and Gaussians whose 
 pixel get a looser gradient bound.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -541,3 +542,44 @@ def test_dist2_knn3_matches_brute_force(P):
             d[torch.arange(d.shape[0]), torch.arange(i, i + d.shape[0])] = float("inf")
             want[i:i + 4096] = d.topk(3, largest=False).values.sum(1).div(3).float().cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-9)
+
+
+def test_training_loop_densifies_and_learns():
+    """f1: the reference's training iteration (train.py:63-146) around the HIP rasterizer on a synthetic scene:
+    the loss goes down, densification / pruning / opacity reset run, PLY export round-trips on device."""
+    import tempfile
+    from dataclasses import replace
+
+    from gaussian_params import Pipe
+    from gaussian_renderer import render
+    from scene import GaussianModel, OptimizationDefaults
+    from train_loop import train
+    torch.manual_seed(0)
+    W, H = 160, 112
+    cams = [c.to(DEV) for c in S.arc_cameras(W, H, 4)]
+    truth = GaussianModel(2); truth.adopt_scene(S.make_scene(4000, W, H, 2, 30, scale_lo=0.01, scale_hi=0.08), device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad():
+        targets = [render(c, truth, Pipe(), bg)["render"].clone() for c in cams]
+
+    class Pcd:                                  # BasicPointCloud-shaped init: noisy subset of the true cloud
+        points = (truth._xyz.detach()[::4] + 0.01 * torch.randn(1000, 3, device=DEV)).cpu().numpy()
+        colors = np.full((1000, 3), 0.5, np.float32)
+    gm = GaussianModel(2)
+    gm.create_from_pcd(Pcd, spatial_lr_scale=1.0, device=DEV)
+    assert gm._scaling.shape == (1000, 3) and torch.isfinite(gm._scaling).all()
+    opt = replace(OptimizationDefaults(), densify_from_iter=20, densification_interval=20, densify_until_iter=150)
+    gm.training_setup(opt)
+    losses, counts = [], []
+    train(gm, cams, targets, opt, Pipe(), bg, iterations=160, scene_extent=3.0,
+          on_iteration=lambda it, loss, g: (losses.append(float(loss.detach())), counts.append(g._xyz.shape[0])))
+    assert np.mean(losses[-10:]) < 0.8 * np.mean(losses[:10]), (losses[:3], losses[-3:])
+    assert max(counts) != 1000 and len(set(counts)) > 2          # the point count changed: densify + prune ran
+    assert gm.active_sh_degree == 0 and all(np.isfinite(losses))
+    gm.reset_opacity()
+    assert float(gm.get_opacity.detach().max()) <= 0.01 + 1e-6
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "point_cloud.ply")
+        gm.save_ply(path)
+        gm2 = GaussianModel(2); gm2.load_ply(path, device=DEV)
+        assert torch.equal(gm2._xyz.detach(), gm._xyz.detach()) and torch.equal(gm2._features_rest.detach(), gm._features_rest.detach())

@@ -1,0 +1,95 @@
+"""CPU tests of the f1/f4 host mirrors: PLY wire format, LR schedule vs the reference's golden values, and the
+parameter-store surgery (clone / split / prune / opacity reset keep parameters and Adam moments aligned)."""
+import os
+
+import numpy as np
+import torch
+
+import scene_synth as S
+from scene import GaussianModel, OptimizationDefaults
+from scene import ply_io
+from scene.gaussian_model import expon_lr
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_lr_schedule_matches_reference():
+    gold = np.load(os.path.join(G, "lr.npz"))
+    f = expon_lr(0.00016, 0.0000016, lr_delay_mult=0.01, max_steps=30000)
+    np.testing.assert_allclose([f(int(s)) for s in gold["steps"]], gold["lr"], rtol=1e-12)
+
+
+def test_optimization_defaults_match_reference():
+    import json
+    ref = json.load(open(os.path.join(G, "params.json")))["optimization"]
+    d = OptimizationDefaults()
+    for k, v in ref.items():
+        if hasattr(d, k) and k != "iterations":
+            assert getattr(d, k) == v, k
+
+
+def _model(P=500, D=3, device="cpu"):
+    gm = GaussianModel(D)
+    gm.adopt_scene(S.make_scene(P, 64, 64, D, 7), device=device)
+    gm.training_setup(OptimizationDefaults())
+    return gm
+
+
+def test_ply_round_trip_and_layout(tmp_path):
+    gm = _model()
+    path = str(tmp_path / "pc" / "point_cloud.ply")
+    gm.save_ply(path)
+    head = open(path, "rb").read(2000).split(b"end_header")[0].decode()
+    props = [l.split()[2] for l in head.splitlines() if l.startswith("property")]
+    assert props == ply_io.property_names(45) and props[:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"]
+    assert "format binary_little_endian 1.0" in head and "element vertex 500" in head
+    raw = np.frombuffer(open(path, "rb").read().split(b"end_header\n", 1)[1], "<f4").reshape(500, -1)
+    # f_rest is channel-major: f_rest_0..14 = red coefficients 1..15
+    np.testing.assert_array_equal(raw[:, 9:9 + 15], gm._features_rest.detach().numpy()[:, :, 0])
+    gm2 = GaussianModel(3)
+    gm2.load_ply(path, device="cpu")
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(getattr(gm, k).detach(), getattr(gm2, k).detach()), k
+    assert gm2.active_sh_degree == 3
+
+
+def test_structural_edits_keep_adam_state_aligned():
+    torch.manual_seed(0)
+    gm = _model(400)
+    for p in gm.optimizer.param_groups:                      # one Adam step so that moments exist
+        p["params"][0].grad = torch.randn_like(p["params"][0])
+    gm.optimizer.step()
+    tag = gm._xyz.detach().clone()
+    m_before = gm.optimizer.state[gm._xyz]["exp_avg"].clone()
+    # prune
+    mask = torch.zeros(400, dtype=torch.bool); mask[::4] = True
+    gm.prune_points(mask)
+    assert gm._xyz.shape[0] == 300 and gm.denom.shape[0] == 300 and gm.max_radii2D.shape[0] == 300
+    assert torch.equal(gm._xyz.detach(), tag[~mask])
+    assert torch.equal(gm.optimizer.state[gm._xyz]["exp_avg"], m_before[~mask])
+    for g in gm.optimizer.param_groups:
+        p = g["params"][0]
+        assert p.shape[0] == 300 and gm.optimizer.state[p]["exp_avg_sq"].shape == p.shape and p is gm._t[g["name"]]
+    # opacity reset: opacities capped at 0.01, fresh moments
+    gm.reset_opacity()
+    assert float(gm.get_opacity.max()) <= 0.01 + 1e-6
+    assert float(gm.optimizer.state[gm._opacity]["exp_avg"].abs().max()) == 0.0
+    # densify: clone small-hot, split big-hot (2 children replace the parent), prune transparent
+    gm.xyz_gradient_accum[:] = 0.0; gm.denom[:] = 1.0
+    gm.xyz_gradient_accum[:40] = 1.0                         # 40 "hot" Gaussians
+    with torch.no_grad():
+        gm._t["scaling"][:20] = np.log(1.0)                  # 20 of them big (> percent_dense * extent = 0.05)
+        gm._t["opacity"][:] = 2.0                            # nothing is transparent
+        gm._t["opacity"][100:110] = -10.0                    # ... except these ten
+    n0 = gm._xyz.shape[0]
+    gm.densify_and_prune(0.0002, 0.005, extent=5.0, max_screen_size=None)
+    assert gm._xyz.shape[0] == n0 + 20 + 2 * 20 - 20 - 10    # +clones, +children, -parents, -transparent
+    for g in gm.optimizer.param_groups:
+        p = g["params"][0]
+        assert gm.optimizer.state[p]["exp_avg"].shape == p.shape
+    assert gm.xyz_gradient_accum.shape[0] == gm._xyz.shape[0] == gm.max_radii2D.shape[0]
+    # capture / restore
+    snap = gm.capture()
+    gm3 = GaussianModel(3)
+    gm3.restore(snap, OptimizationDefaults())
+    assert torch.equal(gm3._xyz.detach(), gm._xyz.detach()) and gm3.active_sh_degree == gm.active_sh_degree
