@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-loop", type=int, default=0, metavar="ITERS",
+                    help="also time ITERS iterations of the full training loop (Adam, densify every 100) on the workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -171,6 +173,10 @@ def main():
             dist.destroy_process_group()
         return
 
+    train_loop = None
+    if world == 1 and args.train_loop > 0:
+        train_loop = _train_loop(args.workload, args.train_loop, dev)
+
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline = _cpu_baseline(scene, cam, cfg)
@@ -192,6 +198,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
     }
+    if train_loop is not None:
+        line["train_loop"] = train_loop
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
@@ -230,6 +238,42 @@ def _frame_stats(model, cam, bg, pipe):
         live = int((screen.abs().sum(1) > 0).sum())
     return dict(num_rendered=fr.R, emitted=emitted, chunks_run=int(fr.plan.chunks_run), live=live,
                 pairs_bwd=int(ncontrib.sum()))
+
+
+def _train_loop(workload, iters, dev):
+    """BASELINE configs[2] taken literally: the full train.py loop (LR schedule, render, loss, backward,
+    densification statistics, densify/prune every 100 iterations, Adam) starting from the workload's cloud, with
+    target views rendered from a second cloud (seed 30) on 8 cameras of a small arc."""
+    from dataclasses import replace
+
+    import scene_synth as S
+    from gaussian_params import Pipe
+    from gaussian_renderer import render
+    from scene import GaussianModel, OptimizationDefaults
+    from train_loop import train
+    cfg = S.CONFIGS[workload]
+    cams = [c.to(dev) for c in S.arc_cameras(cfg["W"], cfg["H"], 8)]
+    bg = torch.zeros(3, device=dev)
+    truth = GaussianModel(cfg["D"])
+    truth.adopt_scene(S.make_scene(cfg["P"], cfg["W"], cfg["H"], cfg["D"], 30), device=dev)
+    with torch.no_grad():
+        targets = [render(c, truth, Pipe(), bg)["render"].clone() for c in cams]
+    del truth
+    gm = GaussianModel(cfg["D"])
+    gm.adopt_scene(S.make_scene(cfg["P"], cfg["W"], cfg["H"], cfg["D"], cfg["seed"]), device=dev)
+    opt = replace(OptimizationDefaults(), densify_from_iter=0)
+    gm.training_setup(opt)
+    warm = min(20, iters // 4)
+    train(gm, cams, targets, opt, Pipe(), bg, iterations=warm, scene_extent=6.0)
+    torch.cuda.synchronize(dev)
+    n0 = gm._xyz.shape[0]
+    t0 = time.perf_counter()
+    train(gm, cams, targets, opt, Pipe(), bg, iterations=warm + iters, first_iter=warm + 1, scene_extent=6.0)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    return {"iterations": iters, "its_per_s": round(iters / dt, 2), "ms_per_it": round(1e3 * dt / iters, 3),
+            "gaussians_start": int(n0), "gaussians_end": int(gm._xyz.shape[0]),
+            "includes": "LR schedule, render, L1/D-SSIM, backward, densification stats, densify+prune every 100 it, Adam"}
 
 
 def _traffic_from_profiles(kernel):
