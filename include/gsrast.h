@@ -168,6 +168,11 @@ int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, f
 int gsr_dist2_workspace_size(int32_t P, size_t *bytes);
 int gsr_dist2_knn3(int32_t P, const float *xyz, float *mean_dist2, void *workspace, void *stream);
 
+/* ---- one torch.optim.Adam step (no weight decay / amsgrad; the reference uses eps = 1e-15,
+ * scene/gaussian_model.py:173) over n contiguous fp32 elements in a single pass.  step = 1 for the first update. */
+int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, int64_t step, void *stream);
+
 /* Test hook for the hand-written radix sort (csrc/gsr_sort.hip): stable sort of n (key, value) u32 pairs on
  * key bits [0, end_bit).  keys0/vals0 hold the input; *result_buffer says which pair of buffers holds the
  * output.  count_on_device != 0 reads n from a device word (as the progressive binning does). */

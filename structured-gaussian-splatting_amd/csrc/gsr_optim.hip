@@ -1,0 +1,62 @@
+// gsr_optim.hip — SURVEY 8f row f1: the optimizer step of the reference's training loop (train.py:140-142,
+// torch.optim.Adam with eps = 1e-15, scene/gaussian_model.py:159-177) as ONE pass over (param, grad, m, v):
+// 16 B read + 12 B written per element, where the foreach implementation makes ~8 passes.
+// Semantics of torch.optim.Adam (no weight decay, no amsgrad):
+//   m <- m + (g - m)(1 - b1);  v <- b2 v + (1 - b2) g^2;  p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#include "gsr_internal.h"
+
+namespace gsr {
+
+constexpr int kAdamBlock = 256;
+
+__global__ __launch_bounds__(kAdamBlock) void k_adam(size_t n, float *__restrict__ p, const float *__restrict__ g,
+                                                     float *__restrict__ m, float *__restrict__ v, float one_minus_b1,
+                                                     float b2, float one_minus_b2, float step_size, float inv_bc2_sqrt, float eps)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * kAdamBlock;
+    for (size_t i = (size_t)blockIdx.x * kAdamBlock + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4 *>(p)[i], mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
+        const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+#define GSR_ADAM1(c)                                                          \
+        mm.c = mm.c + (gg.c - mm.c) * one_minus_b1;                           \
+        vv.c = vv.c * b2 + one_minus_b2 * gg.c * gg.c;                        \
+        pp.c = pp.c - step_size * (mm.c / (sqrtf(vv.c) * inv_bc2_sqrt + eps));
+        GSR_ADAM1(x) GSR_ADAM1(y) GSR_ADAM1(z) GSR_ADAM1(w)
+        reinterpret_cast<float4 *>(p)[i] = pp; reinterpret_cast<float4 *>(m)[i] = mm; reinterpret_cast<float4 *>(v)[i] = vv;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * kAdamBlock + threadIdx.x; i < n; i += stride) {
+        float mm = m[i], vv = v[i];
+        const float gg = g[i];
+        mm = mm + (gg - mm) * one_minus_b1;
+        vv = vv * b2 + one_minus_b2 * gg * gg;
+        p[i] = p[i] - step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+        m[i] = mm; v[i] = vv;
+    }
+#undef GSR_ADAM1
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
+                             float beta2, float eps, int64_t step, void *stream)
+{
+    if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) {
+        set_error("gsr_adam_step: bad argument");
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (n == 0) return GSR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    size_t blocks = ((size_t)n / 4 + kAdamBlock - 1) / kAdamBlock;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    ProfileScope prof("adam", s);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(kAdamBlock), 0, s, (size_t)n, param, grad, exp_avg, exp_avg_sq, 1.f - beta1,
+                       beta2, 1.f - beta2, step_size, inv_bc2_sqrt, eps);
+    GSR_LAUNCH_CHECK("adam", false, s);
+    return GSR_OK;
+}

@@ -60,7 +60,7 @@ class DebugViews(C.Structure):
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
            "gsr_forward_render", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward",
-           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3")
+           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step")
 
 _lib = None
 
@@ -250,3 +250,9 @@ def dist2_knn3(xyz: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(pts.device):
         _check(load().gsr_dist2_knn3(C.c_int32(P), _ptr(pts), _ptr(out), _ptr(ws), _stream(pts.device)), "gsr_dist2_knn3")
     return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    _check(load().gsr_adam_step(C.c_int64(param.numel()), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), C.c_float(lr),
+                                C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_int64(int(step)),
+                                _stream(param.device)), "gsr_adam_step")

@@ -166,7 +166,12 @@ class GaussianModel:
         self.denom = torch.zeros(P, 1, device=self.device)
         lrs = dict(xyz=opt.position_lr_init * self.spatial_lr_scale, f_dc=opt.feature_lr, f_rest=opt.feature_lr / 20.0,
                    opacity=opt.opacity_lr, scaling=opt.scaling_lr, rotation=opt.rotation_lr)
-        self.optimizer = torch.optim.Adam([{"params": [self._t[k]], "lr": lrs[k], "name": k} for k in GROUPS], lr=0.0, eps=1e-15)
+        groups = [{"params": [self._t[k]], "lr": lrs[k], "name": k} for k in GROUPS]
+        if self.device.type == "cuda" and getattr(opt, "fused_adam", True):
+            from fused_adam import FusedAdam          # same state layout as torch.optim.Adam, one kernel per tensor
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self._xyz_lr = expon_lr(opt.position_lr_init * self.spatial_lr_scale, opt.position_lr_final * self.spatial_lr_scale,
                                 lr_delay_mult=opt.position_lr_delay_mult, max_steps=opt.position_lr_max_steps)
 

@@ -583,3 +583,24 @@ def test_training_loop_densifies_and_learns():
         gm.save_ply(path)
         gm2 = GaussianModel(2); gm2.load_ply(path, device=DEV)
         assert torch.equal(gm2._xyz.detach(), gm._xyz.detach()) and torch.equal(gm2._features_rest.detach(), gm._features_rest.detach())
+
+
+def test_fused_adam_matches_torch_adam():
+    """csrc/gsr_optim.hip against torch.optim.Adam (the reference's optimizer, eps = 1e-15) over several steps,
+    odd sizes included; state_dict layout is interchangeable."""
+    from fused_adam import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(1000, 3), (1001, 15, 3), (7,), (1, 1)]
+    ref_p = [torch.randn(*s, device=DEV).requires_grad_(True) for s in shapes]
+    fus_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    mk = lambda ps: [{"params": [p], "lr": 0.01 * (i + 1), "name": str(i)} for i, p in enumerate(ps)]
+    ref, fus = torch.optim.Adam(mk(ref_p), lr=0.0, eps=1e-15), FusedAdam(mk(fus_p), lr=0.0, eps=1e-15)
+    for it in range(6):
+        for a, b in zip(ref_p, fus_p):
+            g = torch.randn_like(a) * (0.0 if it == 3 else 1.0)       # a zero-gradient step too
+            a.grad, b.grad = g.clone(), g.clone()
+        ref.step(); fus.step()
+    for a, b in zip(ref_p, fus_p):
+        assert (a - b).abs().max() <= 2e-6 * max(1.0, float(a.abs().max()))
+        assert (ref.state[a]["exp_avg_sq"] - fus.state[b]["exp_avg_sq"]).abs().max() <= 1e-6
+    ref.load_state_dict(fus.state_dict())                              # same layout
