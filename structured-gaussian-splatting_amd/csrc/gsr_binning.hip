@@ -8,9 +8,10 @@
 // 1.4 M of the 43.8 M instances can ever touch a pixel.  So:
 //
 //   1. sort the P Gaussians ONCE by depth (32-bit keys, invisible ones last)           [P-sized]
-//   2. inclusive scan of tiles touched in depth order; plan depth chunks with cumulative instance
-//      targets R/16, R/4, R (first chunk at least 1 M instances): every chunk costs ~16 small launches
-//      (~100 us of fixed time) while an instance costs ~0.1 ns, so few and large chunks win    [P-sized]
+//   2. inclusive scan of tiles touched in depth order; plan depth chunks by cumulative instance count:
+//      the first holds ~384 instances per tile of the slab (at least 1 M, at most R/8), each further one
+//      4x more: every chunk costs ~16 small launches (~100 us of fixed time) while an instance costs
+//      ~0.1 ns, so few and large chunks win, but tiles saturate after a few hundred splats    [P-sized]
 //   3. per chunk: count the instances each Gaussian emits (tiles of its rectangle that are OPEN and that its
 //      alpha >= 1/255 ellipse can reach: exact tile culling), scan, emit (tile id, slot) pairs in depth
 //      order, stable radix sort on the tile id only (2 passes of 8 bits), tile ranges, blend
@@ -27,8 +28,9 @@
 namespace gsr {
 
 constexpr uint32_t kMinFirstChunk = 1u << 20;    // instances in the first depth chunk (at least)
-constexpr int kFirstChunkDiv = 16;               // first chunk = R / 16 ...
-constexpr int kChunkGrowthLog2 = 2;              // ... then x4 per chunk: R/16, R/4, R (three chunks at most)
+constexpr int kFirstChunkDiv = 8;                // first chunk <= R / 8 ...
+constexpr int kFirstChunkPerTile = 384;          // ... and ~384 instances per tile: tiles saturate after a few hundred splats
+constexpr int kChunkGrowthLog2 = 2;              // then x4 per chunk
 
 GeomWS carve_geom(void *base, int P)
 {
@@ -119,7 +121,8 @@ int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 // ---- chunk plan (one thread): V by binary search on the sorted keys, chunk boundaries by binary search on
 // the inclusive scan.  Cumulative targets double: first, 2 first, 4 first, ... with the last chunk taking
 // everything that is left.
-__global__ void k_chunk_plan(int P, const uint32_t *__restrict__ sorted_keys, const uint32_t *__restrict__ offs_full, Ctrl *ctrl)
+__global__ void k_chunk_plan(int P, int n_tiles, const uint32_t *__restrict__ sorted_keys, const uint32_t *__restrict__ offs_full,
+                             Ctrl *ctrl)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int lo = 0, hi = P;                                   // V = first rank with key == 0xFFFFFFFF
@@ -128,7 +131,8 @@ __global__ void k_chunk_plan(int P, const uint32_t *__restrict__ sorted_keys, co
     const uint32_t R = ctrl->R_total;
     ctrl->V = V;
     ctrl->open_count = 0;
-    uint32_t first = R / (uint32_t)kFirstChunkDiv;
+    uint32_t first = (uint32_t)kFirstChunkPerTile * (uint32_t)n_tiles;
+    if (first > R / (uint32_t)kFirstChunkDiv) first = R / (uint32_t)kFirstChunkDiv;
     if (first < kMinFirstChunk) first = kMinFirstChunk;
     uint32_t nchunks = 0;
     ctrl->bnd[0] = 0;
@@ -158,7 +162,7 @@ __global__ void k_chunk_plan(int P, const uint32_t *__restrict__ sorted_keys, co
 int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 {
     ProfileScope prof("chunk_plan", s);
-    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(64), 0, s, f.P, ws.sort_keys[0], ws.offs_full, ws.ctrl);
+    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(64), 0, s, f.P, (f.ty1 - f.ty0) * f.Gx, ws.sort_keys[0], ws.offs_full, ws.ctrl);
     GSR_LAUNCH_CHECK("chunk_plan", debug, s);
     return GSR_OK;
 }
