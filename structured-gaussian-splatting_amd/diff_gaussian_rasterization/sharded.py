@@ -101,20 +101,26 @@ class _Comm:
 
     def __init__(self, dist, world, rank, group=None):
         self.dist, self.world, self.rank, self.group = dist, world, rank, group
-        self.native_rs = dist.get_backend(group) != "gloo"
+        self.gloo = dist.get_backend(group) == "gloo"      # tests only: device tensors are staged through the host
+        self.native_rs = not self.gloo
 
     def all_gather(self, shard: torch.Tensor) -> torch.Tensor:
         """[n, ...] per rank -> [world * n, ...]."""
-        out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        dev = shard.device
+        if self.gloo and dev.type != "cpu":
+            return self.all_gather(shard.cpu()).to(dev)
+        out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=dev)
         self.dist.all_gather_into_tensor(out, shard.contiguous(), group=self.group)
         return out
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.gloo and t.device.type != "cpu":
+            return self.all_reduce_sum(t.cpu()).to(t.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
     def max_int(self, value: int, device) -> int:
-        t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+        t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if self.gloo else device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
@@ -125,9 +131,10 @@ class _Comm:
             out = torch.empty((n,) + tuple(full.shape[1:]), dtype=full.dtype, device=full.device)
             self.dist.reduce_scatter_tensor(out, full.contiguous(), op=self.dist.ReduceOp.SUM, group=self.group)
             return out
-        full = full.contiguous().clone()            # gloo has no reduce_scatter: all_reduce + slice (tests only)
+        dev = full.device                           # gloo has no reduce_scatter: all_reduce + slice (tests only)
+        full = full.contiguous().cpu().clone() if dev.type != "cpu" else full.contiguous().clone()
         self.dist.all_reduce(full, op=self.dist.ReduceOp.SUM, group=self.group)
-        return full[self.rank * n:(self.rank + 1) * n].clone()
+        return full[self.rank * n:(self.rank + 1) * n].clone().to(dev)
 
 
 class _ShardedRasterize(torch.autograd.Function):
