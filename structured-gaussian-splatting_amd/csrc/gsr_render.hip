@@ -108,21 +108,24 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
     const float fx = (float)px;
     const size_t N = (size_t)f.W * f.H;
 
-    float fy[kStrips], T[kStrips], Cr[kStrips], Cg[kStrips], Cb[kStrips];
+    // Per pixel: Tl = live transmittance (0 once the pixel has taken the cut-off), Tf = transmittance to report
+    // (frozen at the cut-off), colour, last contributor.  A rejected splat runs the same arithmetic with
+    // alpha = 0, which leaves everything unchanged, so the only selects are on alpha, on the stop decision and
+    // on the contributor index.
+    float fy[kStrips], Tl[kStrips], Tf[kStrips], Cr[kStrips], Cg[kStrips], Cb[kStrips];
     int last[kStrips];
-    bool done[kStrips];
 #pragma unroll
     for (int k = 0; k < kStrips; ++k) {
         const int py = py0 + 4 * k;
         fy[k] = (float)py;
         const bool inside = px < f.W && py < f.H;
-        T[k] = 1.f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = 0;
-        done[k] = !inside;
+        Tf[k] = 1.f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = 0;
+        Tl[k] = inside ? 1.f : 0.f;
         if (c > 0 && inside) {
             const size_t pix = (size_t)py * f.W + px;
             const float ts = T_state[pix];
-            T[k] = fabsf(ts);
-            done[k] = ts < 0.f;
+            Tf[k] = fabsf(ts);
+            Tl[k] = ts < 0.f ? 0.f : ts;
             Cr[k] = out_color[pix]; Cg[k] = out_color[N + pix]; Cb[k] = out_color[2 * N + pix];
             last[k] = last_enc[pix];
         }
@@ -131,8 +134,8 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
     const int n_total = (int)(rng.y - rng.x);
     const int enc_base = (c + 1) << kLastShift;
     for (int base = 0; base < n_total; base += kWave) {
-        const bool all_done = done[0] && done[1] && done[2] && done[3];
-        if (__ballot(!all_done) == 0ull) break;
+        const bool any_live = (Tl[0] != 0.f) || (Tl[1] != 0.f) || (Tl[2] != 0.f) || (Tl[3] != 0.f);
+        if (__ballot(any_live) == 0ull) break;
         const int n = min(kWave, n_total - base);
         __syncthreads();
         if (lane < n) {
@@ -154,20 +157,20 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
                 const float dy = a.y - fy[k];
                 const float power = -0.5f * (axx + b.x * dy * dy) - bx * dy;
                 const float alpha = fminf((float)GSR_ALPHA_MAX, b.y * fast_exp(power));
-                bool valid = !done[k] && !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
-                const float test_T = T[k] * (1.f - alpha);
-                const bool stop = valid && (test_T < (float)GSR_T_CUTOFF);
-                done[k] = done[k] || stop;
-                valid = valid && !stop;
-                const float w = valid ? alpha * T[k] : 0.f;
+                const bool keep = !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
+                const float ae = keep ? alpha : 0.f;
+                const float test_T = Tl[k] * (1.f - ae);              // == Tl when rejected, 0 when already done
+                const bool stop = test_T < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
+                const float w = stop ? 0.f : ae * Tl[k];               // the stopping splat is NOT composited (A.8)
                 Cr[k] += b.z * w; Cg[k] += b.w * w; Cb[k] += cb * w;
-                T[k] = valid ? test_T : T[k];
-                last[k] = valid ? contributor : last[k];
+                Tf[k] = stop ? Tf[k] : test_T;
+                Tl[k] = stop ? 0.f : test_T;
+                last[k] = (keep && !stop) ? contributor : last[k];
             }
         }
     }
-    const bool all_done = done[0] && done[1] && done[2] && done[3];
-    const bool closing = __ballot(!all_done) == 0ull;
+    const bool any_live = (Tl[0] != 0.f) || (Tl[1] != 0.f) || (Tl[2] != 0.f) || (Tl[3] != 0.f);
+    const bool closing = __ballot(any_live) == 0ull;
     const bool finalize = closing || finalize_all != 0;
     const float bg0 = finalize ? bg[0] : 0.f, bg1 = finalize ? bg[1] : 0.f, bg2 = finalize ? bg[2] : 0.f;
 #pragma unroll
@@ -175,10 +178,10 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
         const int py = py0 + 4 * k;
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
-            out_color[pix] = Cr[k] + T[k] * bg0;
-            out_color[N + pix] = Cg[k] + T[k] * bg1;
-            out_color[2 * N + pix] = Cb[k] + T[k] * bg2;
-            T_state[pix] = done[k] ? -T[k] : T[k];
+            out_color[pix] = Cr[k] + Tf[k] * bg0;
+            out_color[N + pix] = Cg[k] + Tf[k] * bg1;
+            out_color[2 * N + pix] = Cb[k] + Tf[k] * bg2;
+            T_state[pix] = Tl[k] == 0.f ? -Tf[k] : Tf[k];
             last_enc[pix] = last[k];
         }
     }
