@@ -146,6 +146,10 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
             sh_rec[3 * lane + 2] = r[2];
         }
         __syncthreads();
+        // Strip pairs (rows 0-7 and 8-15 of the tile) whose 128 pixels have all taken the cut-off are skipped for
+        // the whole batch: a wave-uniform flag per pair, evaluated once per 64 splats.
+        const bool pair_live0 = __ballot((Tl[0] != 0.f) || (Tl[1] != 0.f)) != 0ull;
+        const bool pair_live1 = __ballot((Tl[2] != 0.f) || (Tl[3] != 0.f)) != 0ull;
         for (int j = 0; j < n; ++j) {
             const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
             const float cb = sh_rec[3 * j + 2].x;
@@ -153,19 +157,23 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
             const float axx = a.z * dx * dx, bx = a.w * dx;
             const int contributor = enc_base | (base + j + 1);
 #pragma unroll
-            for (int k = 0; k < kStrips; ++k) {
-                const float dy = a.y - fy[k];
-                const float power = -0.5f * (axx + b.x * dy * dy) - bx * dy;
-                const float alpha = fminf((float)GSR_ALPHA_MAX, b.y * fast_exp(power));
-                const bool keep = !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
-                const float ae = keep ? alpha : 0.f;
-                const float test_T = Tl[k] * (1.f - ae);              // == Tl when rejected, 0 when already done
-                const bool stop = test_T < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
-                const float w = stop ? 0.f : ae * Tl[k];               // the stopping splat is NOT composited (A.8)
-                Cr[k] += b.z * w; Cg[k] += b.w * w; Cb[k] += cb * w;
-                Tf[k] = stop ? Tf[k] : test_T;
-                Tl[k] = stop ? 0.f : test_T;
-                last[k] = (keep && !stop) ? contributor : last[k];
+            for (int p = 0; p < 2; ++p) {
+                if (!(p == 0 ? pair_live0 : pair_live1)) continue;
+#pragma unroll
+                for (int k = 2 * p; k < 2 * p + 2; ++k) {
+                    const float dy = a.y - fy[k];
+                    const float power = -0.5f * (axx + b.x * dy * dy) - bx * dy;
+                    const float alpha = fminf((float)GSR_ALPHA_MAX, b.y * fast_exp(power));
+                    const bool keep = !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
+                    const float ae = keep ? alpha : 0.f;
+                    const float test_T = Tl[k] * (1.f - ae);              // == Tl when rejected, 0 when already done
+                    const bool stop = test_T < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
+                    const float w = stop ? 0.f : ae * Tl[k];               // the stopping splat is NOT composited (A.8)
+                    Cr[k] += b.z * w; Cg[k] += b.w * w; Cb[k] += cb * w;
+                    Tf[k] = stop ? Tf[k] : test_T;
+                    Tl[k] = stop ? 0.f : test_T;
+                    last[k] = (keep && !stop) ? contributor : last[k];
+                }
             }
         }
     }
