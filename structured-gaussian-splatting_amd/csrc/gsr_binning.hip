@@ -216,7 +216,9 @@ __device__ __forceinline__ bool instance_wanted(const FrameK &f, const TileRect 
     if (i >= total) return false;
     const int tx = t.x0 + i % w, ty = t.y0 + i / w;
     tile = (uint32_t)(ty * f.Gx + tx);
-    return open[tile] != 0u && tile_may_contribute(a.x, a.y, a.z, a.w, b.x, b.y, tx, ty);
+    float A, B, C, op;
+    unscale_conic(a.z, a.w, b.x, b.y, A, B, C, op);
+    return open[tile] != 0u && tile_may_contribute(a.x, a.y, A, B, C, op, tx, ty);
 }
 
 __global__ __launch_bounds__(kBinBlock) void k_count_open(FrameK f, int r0, int r1, const uint32_t *__restrict__ order,

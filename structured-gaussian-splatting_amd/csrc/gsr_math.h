@@ -27,9 +27,15 @@ struct FrameK {            // kernel-side scalars derived from gsr_frame_desc
     float tanfovx, tanfovy, focal_x, focal_y, scale_modifier;
 };
 
-struct Splat {             // 48-byte record consumed by the render kernels (3 x float4)
-    float x, y, cA, cB;    // pixel-space mean, conic A, B
-    float cC, op, r, g;    // conic C, opacity, colour r g
+// 48-byte record consumed by the binning and blend kernels (3 x float4).  The conic and the opacity are stored
+// PRE-SCALED so that a pixel's alpha is ONE exp2 of a two-FMA quadratic:
+//   qA = -0.5 log2(e) A,  qB = -log2(e) B,  qC = -0.5 log2(e) C,  lop = log2(opacity)
+//   p(d) = qA dx^2 + qB dx dy + qC dy^2 + lop  =  log2(opacity * exp(power(d)))      =>  alpha = min(0.99, 2^p)
+//   power(d) > 0  <=>  p > lop.
+constexpr float kLog2e = 1.4426950408889634f;
+struct Splat {
+    float x, y, cA, cB;    // pixel-space mean, qA, qB
+    float cC, op, r, g;    // qC, lop, colour r g
     float b, depth, rect_x, rect_y; // rect_x / rect_y: bit patterns of (x0 | x1 << 16), (y0 | y1 << 16): the tile
                                     // rectangle the binning walks (tight_rect below), slab-clipped
 };
@@ -57,6 +63,12 @@ GSR_HD TileRect tile_rect(float px, float py, float radius, const FrameK &f)
 // power(d) = -1/2 (A dx^2 + C dy^2) - B dx dy over the tile's pixel-centre rectangle (a superset of its 256
 // pixels) is compared with the power at which alpha reaches 1/255, minus a margin that covers the blend
 // kernels' fp32 evaluation error (few 1e-7 of the term magnitudes) and their exp2-based exponential (1e-6).
+// A, B, C, opacity back from the pre-scaled record fields.
+GSR_HD void unscale_conic(float qA, float qB, float qC, float lop, float &A, float &B, float &C, float &op)
+{
+    A = qA * (-2.f / kLog2e); B = qB * (-1.f / kLog2e); C = qC * (-2.f / kLog2e); op = exp2f(lop);
+}
+
 GSR_HD bool tile_may_contribute(float sx, float sy, float A, float B, float C, float op, int tile_x, int tile_y)
 {
     if (op < (float)GSR_ALPHA_MIN) return false;             // op * G <= op < 1/255 for every G <= 1
@@ -311,8 +323,8 @@ GSR_HD void preprocess_one(const FrameK &f, const float *V, const float *PV, con
     }
     o.radius = (int)my_radius;
     o.s.x = px; o.s.y = py;
-    o.s.cA = e.c * det_inv; o.s.cB = -e.b * det_inv; o.s.cC = e.a * det_inv;
-    o.s.op = opacity;
+    o.s.cA = (-0.5f * kLog2e) * (e.c * det_inv); o.s.cB = -kLog2e * (-e.b * det_inv); o.s.cC = (-0.5f * kLog2e) * (e.a * det_inv);
+    o.s.op = log2f(opacity);
     o.s.r = rgb[0]; o.s.g = rgb[1]; o.s.b = rgb[2];
     o.s.depth = pv[2];
     TileRect t = tight_rect(r, px, py, e.a, e.c, opacity);

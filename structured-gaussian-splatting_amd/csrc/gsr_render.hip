@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
             const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
             const float cb = sh_rec[3 * j + 2].x;
             const float dx = a.x - fx;
-            const float axx = a.z * dx * dx, bx = a.w * dx;
+            const float axx = a.z * dx * dx + b.y, bx = a.w * dx;         // record is pre-scaled: p = log2(op exp(power))
             const int contributor = enc_base | (base + j + 1);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
 #pragma unroll
                 for (int k = 2 * p; k < 2 * p + 2; ++k) {
                     const float dy = a.y - fy[k];
-                    const float power = -0.5f * (axx + b.x * dy * dy) - bx * dy;
-                    const float alpha = fminf((float)GSR_ALPHA_MAX, b.y * fast_exp(power));
-                    const bool keep = !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
+                    const float lp = (b.x * dy + bx) * dy + axx;
+                    const float alpha = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(lp));
+                    const bool keep = !(lp > b.y) && !(alpha < (float)GSR_ALPHA_MIN);       // power > 0  <=>  lp > lop
                     const float ae = keep ? alpha : 0.f;
                     const float test_T = Tl[k] * (1.f - ae);              // == Tl when rejected, 0 when already done
                     const bool stop = test_T < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
@@ -291,16 +291,20 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
                     const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
                     const float cb = sh_rec[3 * j + 2].x;
                     const float dx = a.x - fx;
-                    const float axx = a.z * dx * dx, bx = a.w * dx;
+                    const float axx = a.z * dx * dx + b.y, bx = a.w * dx;       // pre-scaled record: lp = log2(op exp(power))
+                    float cA, cB, cC, opac;                                      // the unscaled conic / opacity (per splat)
+                    unscale_conic(a.z, a.w, b.x, b.y, cA, cB, cC, opac);
+                    const float inv_op = fast_rcp(opac);
                     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
                     bool any_valid = false;
 #pragma unroll
                     for (int k = 0; k < kStrips; ++k) {
                         const float dy = a.y - fy[k];
-                        const float power = -0.5f * (axx + b.x * dy * dy) - bx * dy;
-                        const float G = fast_exp(fminf(power, 0.f));         // power > 0 lanes are rejected; keep G finite
-                        const float alpha = fminf((float)GSR_ALPHA_MAX, b.y * G);
-                        const bool valid = (pos < limit[k]) && !(power > 0.f) && !(alpha < (float)GSR_ALPHA_MIN);
+                        const float lp = (b.x * dy + bx) * dy + axx;
+                        const float araw = __builtin_amdgcn_exp2f(fminf(lp, b.y));   // = op * G; power > 0 lanes are rejected
+                        const float G = araw * inv_op;
+                        const float alpha = fminf((float)GSR_ALPHA_MAX, araw);
+                        const bool valid = (pos < limit[k]) && !(lp > b.y) && !(alpha < (float)GSR_ALPHA_MIN);
                         any_valid = any_valid || valid;
                         // Rejected pixels run the same arithmetic with alpha = 0 and G = 0: T, the colour behind and
                         // every partial sum then stay exactly unchanged, so only these two values need a select.
@@ -316,10 +320,10 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
                         ar[k] += ae * dr; ag[k] += ae * dg; ab[k] += ae * db;
                         dL_dalpha = dL_dalpha * Tn_ + bgterm[k] * inv1ma;
                         const float gdx = Ge * dx, gdy = Ge * dy;
-                        const float tG = b.y * dL_dalpha;                     // dL/dG (times G through gdx, gdy)
+                        const float tG = opac * dL_dalpha;                    // dL/dG (times G through gdx, gdy)
                         const float tx = tG * gdx, ty = tG * gdy;
-                        s0 -= tx * a.z + ty * a.w;                            // dL/dG * dG/ddelx
-                        s1 -= ty * b.x + tx * a.w;
+                        s0 -= tx * cA + ty * cB;                              // dL/dG * dG/ddelx
+                        s1 -= ty * cC + tx * cB;
                         s2 += tx * dx;
                         s3 += tx * dy;
                         s4 += ty * dy;

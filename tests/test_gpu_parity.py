@@ -20,7 +20,7 @@ import torch
 
 import oracle
 import scene_synth as S
-from util import cov3d_from, raster_kwargs
+from util import cov3d_from, raster_kwargs, unscale_records
 
 pytestmark = pytest.mark.gpu
 
@@ -199,7 +199,7 @@ def test_intermediates_bit_exact_vs_oracle_f32():
     assert frame.R == int(tiles_dev.sum()) <= fr.num_rendered and frame.plan.num_visible == int((fr.radii > 0).sum())
     # depth order: visible Gaussians by (binary32 depth, index); device depth is FMA-contracted, so allow
     # swaps only between depths that differ by a few ulp
-    rec = v["splat_records"].cpu().numpy()
+    rec = unscale_records(v["splat_records"].cpu().numpy())
     order = v["depth_order"].cpu().numpy().astype(np.int64)
     V = frame.plan.num_visible
     vis = np.nonzero(fr.radii > 0)[0]

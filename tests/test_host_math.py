@@ -14,7 +14,7 @@ import torch
 
 import oracle
 import scene_synth as S
-from util import cov3d_from, raster_kwargs
+from util import cov3d_from, raster_kwargs, unscale_records
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -71,10 +71,10 @@ def test_preprocess_matches_oracle(hh, mode, D):
     np.testing.assert_array_equal(((x1 - x0) * (y1 - y0))[v], got["tiles"][v])
     vis = fr.radii > 0
     assert vis.sum() > 1000
-    rec = got["rec"][vis]
+    rec = unscale_records(got["rec"])[vis]
     np.testing.assert_allclose(rec[:, 0:2], fr.xy[vis], rtol=1e-6, atol=1e-4)
     np.testing.assert_allclose(rec[:, 2:5], fr.conic_opacity[vis, :3], rtol=2e-5, atol=1e-7)
-    np.testing.assert_allclose(rec[:, 5], fr.conic_opacity[vis, 3], rtol=0, atol=0)
+    np.testing.assert_allclose(rec[:, 5], fr.conic_opacity[vis, 3], rtol=2e-6, atol=0)
     np.testing.assert_allclose(rec[:, 6:9], fr.rgb[vis], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(rec[:, 9], fr.depth[vis], rtol=1e-6)
     bits = (fr.clamped[:, 0] | (fr.clamped[:, 1] << 1) | (fr.clamped[:, 2] << 2)).astype(np.uint8)

@@ -51,3 +51,17 @@ def assert_close_masked(got, want, mask_strict, atol, rtol, what, loose_atol=Non
                            f"max err {err[mask_strict].max():.3e}")
     if loose_atol is not None and (~mask_strict).any():
         assert err[~mask_strict].max() <= loose_atol, f"{what}: non-strict max err {err[~mask_strict].max():.3e}"
+
+
+LOG2E = 1.4426950408889634
+
+
+def unscale_records(rec):
+    """Device splat records store the conic and opacity pre-scaled (csrc/gsr_math.h Splat): return a copy with
+    columns 2..5 = conic A, B, C and opacity as the oracle reports them."""
+    out = np.array(rec, dtype=np.float32, copy=True)
+    out[:, 2] = rec[:, 2] * np.float32(-2.0 / LOG2E)
+    out[:, 3] = rec[:, 3] * np.float32(-1.0 / LOG2E)
+    out[:, 4] = rec[:, 4] * np.float32(-2.0 / LOG2E)
+    out[:, 5] = np.exp2(rec[:, 5].astype(np.float64)).astype(np.float32)
+    return out
