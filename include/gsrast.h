@@ -124,10 +124,14 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
 
 /* Second half of `_C.rasterize_gaussians_backward`: per-Gaussian backward (2D covariance, projection,
  * SH, 3D covariance) for Gaussians [g_begin, g_end).  Every non-NULL output row in that range is
- * written (zeros for invisible Gaussians and for SH coefficients above the active degree). */
+ * written (zeros for invisible Gaussians and for SH coefficients above the active degree).
+ * binned_ranks: a HINT — the number of leading depth ranks outside which `screen_grads` is known to be all
+ * zero (plan->chunk_rank_begin[plan->chunks_run] for gradients that come from THIS frame's
+ * gsr_backward_render, or the maximum over ranks after a multi-GPU sum), or -1 for "unknown".  When the whole
+ * range is requested and the prefix is short the outputs are memset and only the prefix is visited. */
 int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g,
                       const int32_t *radii, const void *geom_ws, const float *screen_grads, int32_t g_begin,
-                      int32_t g_end, const gsr_grads *out, void *stream);
+                      int32_t g_end, int32_t binned_ranks, const gsr_grads *out, void *stream);
 
 /* `_C.mark_visible`: present[i] = 1 iff Gaussian i passes the near-plane test (A.1). */
 int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

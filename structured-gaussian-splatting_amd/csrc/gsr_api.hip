@@ -254,8 +254,8 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
 }
 
 int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, const int32_t *radii,
-                      const void *geom_ws, const float *screen_grads, int32_t g_begin, int32_t g_end, const gsr_grads *out,
-                      void *stream)
+                      const void *geom_ws, const float *screen_grads, int32_t g_begin, int32_t g_end, int32_t binned_ranks,
+                      const gsr_grads *out, void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
@@ -266,7 +266,8 @@ int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const g
     if (!radii || !geom_ws || !screen_grads) { set_error("gsr_backward_geom: NULL argument"); return GSR_ERR_INVALID_ARGUMENT; }
     const FrameK f = make_frame(*desc);
     GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
-    return launch_geom_bwd(f, *cam, *g, radii, gw, screen_grads, g_begin, g_end, *out, desc->debug != 0, (hipStream_t)stream);
+    return launch_geom_bwd(f, *cam, *g, radii, gw, screen_grads, g_begin, g_end, binned_ranks, *out, desc->debug != 0,
+                           (hipStream_t)stream);
 }
 
 int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

@@ -118,7 +118,8 @@ def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.T
     return screen[:P]
 
 
-def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int = 0, g1: Optional[int] = None):
+def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int = 0, g1: Optional[int] = None,
+                            binned_ranks: Optional[int] = None):
     """K8 + K9 on Gaussians [g0, g1).  `needs` = (means3D, means2D, sh, colors, opacities, scales, rotations,
     cov3D) booleans.  Returns the 8 gradient tensors (None where not needed / not applicable)."""
     P, M, dev = fr.desc.P, fr.M, fr.device
@@ -141,7 +142,10 @@ def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int =
                     N._ptr(g_rot), N._ptr(g_cov))
     if P > 0 and g1 > g0:
         with torch.cuda.device(dev):
-            N.backward_geom(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, g0, g1, grads, dev)
+            if binned_ranks is None:        # gradients of this very frame: its own binned depth prefix
+                plan = fr.plan
+                binned_ranks = int(plan.chunk_rank_begin[plan.chunks_run]) if plan.num_rendered > 0 and plan.chunks_run > 0 else 0
+            N.backward_geom(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, g0, g1, grads, dev, binned_ranks)
     return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov
 
 

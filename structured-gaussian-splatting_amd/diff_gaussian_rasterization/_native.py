@@ -150,10 +150,11 @@ def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, plan: Fram
            "gsr_backward_render")
 
 
-def backward_geom(desc, cam: Camera, g: Gaussians, radii, geom_ws, screen_grads, g0, g1, grads: Grads, device):
+def backward_geom(desc, cam: Camera, g: Gaussians, radii, geom_ws, screen_grads, g0, g1, grads: Grads, device,
+                  binned_ranks: int = -1):
     _check(load().gsr_backward_geom(C.byref(desc), C.byref(cam), C.byref(g), _ptr(radii), _ptr(geom_ws),
-                                    _ptr(screen_grads), C.c_int32(g0), C.c_int32(g1), C.byref(grads), _stream(device)),
-           "gsr_backward_geom")
+                                    _ptr(screen_grads), C.c_int32(g0), C.c_int32(g1), C.c_int32(binned_ranks), C.byref(grads),
+                                    _stream(device)), "gsr_backward_geom")
 
 
 def mark_visible(means3D, viewmatrix, projmatrix, present):

@@ -83,9 +83,9 @@ class NativeBackend:
         from . import rasterize_backward_screen
         return rasterize_backward_screen(frame, grad_color)
 
-    def backward_geom(self, frame, screen, needs, g0, g1):
+    def backward_geom(self, frame, screen, needs, g0, g1, binned_ranks=-1):
         from . import rasterize_backward_geom
-        return rasterize_backward_geom(frame, screen, needs, g0, g1)
+        return rasterize_backward_geom(frame, screen, needs, g0, g1, binned_ranks=binned_ranks)
 
     def binned_prefix(self, frame):
         """(depth_order[P] as a device tensor, number of leading depth ranks that may own gradient rows)."""
@@ -185,7 +185,7 @@ class _ShardedRasterize(torch.autograd.Function):
                     screen = partial.clone()
                     screen[idx] = comm.all_reduce_sum(partial[idx].contiguous())
             # (3) every rank runs the whole geometry backward: full parameter gradients, no further collective
-            out = list(backend.backward_geom(frame, screen, needs, 0, P))
+            out = list(backend.backward_geom(frame, screen, needs, 0, P, n_max if order is not None else -1))
         else:
             g0, g1, slen = gaussian_shard(P, comm.world, comm.rank)
             padded = torch.zeros(comm.world * slen, SCREEN_STRIDE, dtype=partial.dtype, device=partial.device)

@@ -50,7 +50,7 @@ class OracleBackend:
         rest = np.setdiff1d(np.arange(fr.P), order)
         return torch.from_numpy(np.concatenate([order, rest])), int(order.size)
 
-    def backward_geom(self, fr, screen, needs, g0, g1):
+    def backward_geom(self, fr, screen, needs, g0, g1, binned_ranks=-1):
         g = fr.backward_geom(screen[:, :9].double().numpy(), g0, g1)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(screen.dtype)
         return (t(g["means3D"]), t(g["means2D"]), t(g["shs"]) if fr.M else None,
