@@ -49,9 +49,16 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
                                                       float *__restrict__ d_mu, float *__restrict__ d_eaa, float *__restrict__ d_eab,
                                                       float *__restrict__ partial_ssim, float *__restrict__ partial_l1)
 {
-    __shared__ float sa[kLI][kLI + 1], sb[kLI][kLI + 1];
-    __shared__ float hz[5][kLI][kLT + 1];
+    // LDS is used twice: first the staged tile + halo of a and b, then (after every thread holds its row-filtered
+    // values in registers) the five row-filtered moment planes OVER the same bytes: 27.7 KB per block instead of
+    // 42 KB, i.e. 5 resident blocks per CU instead of 3.
+    constexpr int kStageFloats = 2 * kLI * (kLI + 1);
+    constexpr int kHzFloats = 5 * kLI * (kLT + 1);
+    __shared__ float lds[kHzFloats > kStageFloats ? kHzFloats : kStageFloats];
     __shared__ float red[4];
+    float (*sa)[kLI + 1] = reinterpret_cast<float (*)[kLI + 1]>(lds);
+    float (*sb)[kLI + 1] = reinterpret_cast<float (*)[kLI + 1]>(lds + kLI * (kLI + 1));
+    float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
     const int ch = blockIdx.z, x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const size_t plane = (size_t)ch * H * W;
     for (int idx = threadIdx.x; idx < kLI * kLI; idx += kLBlock) {
@@ -62,15 +69,37 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
         sb[r][c] = in ? b[plane + (size_t)y * W + x] : 0.f;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kLI * kLT; idx += kLBlock) {
-        const int r = idx / kLT, c = idx % kLT;
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f, m4 = 0.f;
+    // this thread's four output pixels: centre values for the L1 term, before the staging area is overwritten
+    float ca[(kLT * kLT) / kLBlock], cbv[(kLT * kLT) / kLBlock];
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const float g = win.g[i], va = sa[r][c + i], vb = sb[r][c + i];
-            m0 += g * va; m1 += g * vb; m2 += g * va * va; m3 += g * vb * vb; m4 += g * va * vb;
+    for (int k = 0; k < (kLT * kLT) / kLBlock; ++k) {
+        const int idx = threadIdx.x + k * kLBlock;
+        ca[k] = sa[idx / kLT + kLH][idx % kLT + kLH];
+        cbv[k] = sb[idx / kLT + kLH][idx % kLT + kLH];
+    }
+    constexpr int kHzIters = (kLI * kLT + kLBlock - 1) / kLBlock;       // 6
+    float m0[kHzIters], m1[kHzIters], m2[kHzIters], m3[kHzIters], m4[kHzIters];
+#pragma unroll
+    for (int it = 0; it < kHzIters; ++it) {
+        const int idx = threadIdx.x + it * kLBlock;
+        m0[it] = m1[it] = m2[it] = m3[it] = m4[it] = 0.f;
+        if (idx < kLI * kLT) {
+            const int r = idx / kLT, c = idx % kLT;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const float g = win.g[i], va = sa[r][c + i], vb = sb[r][c + i];
+                m0[it] += g * va; m1[it] += g * vb; m2[it] += g * va * va; m3[it] += g * vb * vb; m4[it] += g * va * vb;
+            }
         }
-        hz[0][r][c] = m0; hz[1][r][c] = m1; hz[2][r][c] = m2; hz[3][r][c] = m3; hz[4][r][c] = m4;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kHzIters; ++it) {
+        const int idx = threadIdx.x + it * kLBlock;
+        if (idx < kLI * kLT) {
+            const int r = idx / kLT, c = idx % kLT;
+            hz[0][r][c] = m0[it]; hz[1][r][c] = m1[it]; hz[2][r][c] = m2[it]; hz[3][r][c] = m3[it]; hz[4][r][c] = m4[it];
+        }
     }
     __syncthreads();
     float s_ssim = 0.f, s_l1 = 0.f;
@@ -93,7 +122,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
             const float inv = 1.f / (B1 * B2);
             const float m = A1 * A2 * inv;
             s_ssim += m;
-            s_l1 += fabsf(sa[r + kLH][c + kLH] - sb[r + kLH][c + kLH]);
+            s_l1 += fabsf(ca[k] - cbv[k]);
             if (d_mu) {
                 const size_t p = plane + (size_t)y * W + x;
                 d_mu[p] = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * m * (B2 - B1) * inv;
@@ -132,8 +161,10 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, flo
                                                       const float *__restrict__ d_eaa, const float *__restrict__ d_eab,
                                                       float *__restrict__ grad_a)
 {
-    __shared__ float sm[3][kLI][kLI + 1];
-    __shared__ float hz[3][kLI][kLT + 1];
+    constexpr int kStageFloats = 3 * kLI * (kLI + 1);
+    __shared__ float lds[kStageFloats];                              // staged maps, then (over the same bytes) row-filtered maps
+    float (*sm)[kLI][kLI + 1] = reinterpret_cast<float (*)[kLI][kLI + 1]>(lds);
+    float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
     const int ch = blockIdx.z, x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const size_t plane = (size_t)ch * H * W;
     for (int idx = threadIdx.x; idx < kLI * kLI; idx += kLBlock) {
@@ -146,15 +177,29 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, flo
         sm[2][r][c] = in ? d_eab[p] : 0.f;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < kLI * kLT; idx += kLBlock) {
-        const int r = idx / kLT, c = idx % kLT;
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    constexpr int kHzIters = (kLI * kLT + kLBlock - 1) / kLBlock;
+    float m0[kHzIters], m1[kHzIters], m2[kHzIters];
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const float g = win.g[i];
-            m0 += g * sm[0][r][c + i]; m1 += g * sm[1][r][c + i]; m2 += g * sm[2][r][c + i];
+    for (int it = 0; it < kHzIters; ++it) {
+        const int idx = threadIdx.x + it * kLBlock;
+        m0[it] = m1[it] = m2[it] = 0.f;
+        if (idx < kLI * kLT) {
+            const int r = idx / kLT, c = idx % kLT;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const float g = win.g[i];
+                m0[it] += g * sm[0][r][c + i]; m1[it] += g * sm[1][r][c + i]; m2[it] += g * sm[2][r][c + i];
+            }
         }
-        hz[0][r][c] = m0; hz[1][r][c] = m1; hz[2][r][c] = m2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kHzIters; ++it) {
+        const int idx = threadIdx.x + it * kLBlock;
+        if (idx < kLI * kLT) {
+            const int r = idx / kLT, c = idx % kLT;
+            hz[0][r][c] = m0[it]; hz[1][r][c] = m1[it]; hz[2][r][c] = m2[it];
+        }
     }
     __syncthreads();
     const float up = upstream ? upstream[0] : 1.f;
