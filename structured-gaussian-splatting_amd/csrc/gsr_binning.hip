@@ -118,39 +118,66 @@ int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
                                  debug, s);
 }
 
-// ---- chunk plan (one thread): V by binary search on the sorted keys, chunk boundaries by binary search on
-// the inclusive scan.  Cumulative targets double: first, 2 first, 4 first, ... with the last chunk taking
-// everything that is left.
-__global__ void k_chunk_plan(int P, int n_tiles, const uint32_t *__restrict__ sorted_keys, const uint32_t *__restrict__ offs_full,
-                             Ctrl *ctrl)
+// ---- chunk plan (one block of 9 waves): wave 0 finds V (first rank whose key is 0xFFFFFFFF), wave 1+c the end
+// of chunk c (first rank whose inclusive tile count exceeds the chunk's cumulative target: first, 4 first,
+// 16 first, ... with the last chunk taking everything that is left).  Each wave runs a 64-ary search, so the
+// dependent-load chain is 4 deep at a million Gaussians instead of 20.
+template <typename Pred>
+__device__ __forceinline__ uint32_t wave_lower_bound(uint32_t n, Pred pred)   // first i in [0,n) with pred(i), else n
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int lo = 0, hi = P;                                   // V = first rank with key == 0xFFFFFFFF
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] != 0xFFFFFFFFu) lo = mid + 1; else hi = mid; }
-    const uint32_t V = (uint32_t)lo;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t step = (hi - lo + 63u) >> 6;
+        const uint32_t seg = lo + lane * step;
+        const bool valid = seg < hi;
+        const uint32_t last = valid ? min(hi, seg + step) - 1u : 0u;            // last element of this lane's segment
+        const unsigned long long m = __ballot(valid && pred(last));
+        if (m == 0ull) return hi;
+        const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
+        hi = __shfl(last, (int)k);
+        lo = lo + k * step;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int P, int n_tiles, const uint32_t *__restrict__ sorted_keys,
+                                                                            const uint32_t *__restrict__ offs_full, Ctrl *ctrl)
+{
+    __shared__ uint32_t sh_V, sh_end[GSR_MAX_CHUNKS];
     const uint32_t R = ctrl->R_total;
-    ctrl->V = V;
-    ctrl->open_count = 0;
+    const int w = threadIdx.x >> 6;
     uint32_t first = (uint32_t)kFirstChunkPerTile * (uint32_t)n_tiles;
     if (first > R / (uint32_t)kFirstChunkDiv) first = R / (uint32_t)kFirstChunkDiv;
     if (first < kMinFirstChunk) first = kMinFirstChunk;
-    uint32_t nchunks = 0;
+    if (w == 0) {
+        const uint32_t V = wave_lower_bound((uint32_t)P, [&](uint32_t i) { return sorted_keys[i] == 0xFFFFFFFFu; });
+        if ((threadIdx.x & 63) == 0) sh_V = V;
+    } else {
+        // invisible Gaussians have a tile count of 0, so the scan is flat beyond V: searching [0,P) and clamping
+        // to V gives the same answer as searching [0,V)
+        const int c = w - 1;
+        const uint64_t target = (uint64_t)first << (kChunkGrowthLog2 * c);
+        uint32_t end = (uint32_t)P;
+        if (c < GSR_MAX_CHUNKS - 1 && target < (uint64_t)R)
+            end = wave_lower_bound((uint32_t)P, [&](uint32_t i) { return (uint64_t)offs_full[i] > target; });
+        if ((threadIdx.x & 63) == 0) sh_end[c] = end;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const uint32_t V = sh_V;
+    ctrl->V = V;
+    ctrl->open_count = 0;
     ctrl->bnd[0] = 0;
     ctrl->chunk_base[0] = 0;
     for (int c = 0; c < GSR_MAX_CHUNKS; ++c) {
         ctrl->chunk_full[c] = 0; ctrl->chunk_R[c] = 0; ctrl->bnd[c + 1] = V; ctrl->chunk_base[c + 1] = 0;
     }
-    uint32_t begin = 0;
+    uint32_t begin = 0, nchunks = 0;
     for (int c = 0; c < GSR_MAX_CHUNKS && begin < V; ++c) {
-        uint32_t end = V;
-        const uint64_t target = (uint64_t)first << (kChunkGrowthLog2 * c);
-        if (c < GSR_MAX_CHUNKS - 1 && target < (uint64_t)R) {
-            int l = (int)begin, h = (int)V;             // first rank whose inclusive count exceeds the target
-            while (l < h) { const int mid = (l + h) >> 1; if ((uint64_t)offs_full[mid] <= target) l = mid + 1; else h = mid; }
-            end = (uint32_t)l;
-            if (end <= begin) end = begin + 1;
-            if (end > V) end = V;
-        }
+        uint32_t end = sh_end[c];
+        if (end <= begin) end = begin + 1;               // every chunk makes progress
+        if (end > V) end = V;
         ctrl->bnd[c + 1] = end;
         ctrl->chunk_full[c] = offs_full[end - 1] - (begin ? offs_full[begin - 1] : 0u);
         begin = end;
@@ -162,7 +189,7 @@ __global__ void k_chunk_plan(int P, int n_tiles, const uint32_t *__restrict__ so
 int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 {
     ProfileScope prof("chunk_plan", s);
-    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(64), 0, s, f.P, (f.ty1 - f.ty0) * f.Gx, ws.sort_keys[0], ws.offs_full, ws.ctrl);
+    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(kWave * (GSR_MAX_CHUNKS + 1)), 0, s, f.P, (f.ty1 - f.ty0) * f.Gx, ws.sort_keys[0], ws.offs_full, ws.ctrl);
     GSR_LAUNCH_CHECK("chunk_plan", debug, s);
     return GSR_OK;
 }
