@@ -160,7 +160,7 @@ def main():
     bytes_per_launch = alg[dom] * args.steps / launches
     achieved = (bytes_per_launch / 1e9) / (dom_ms / 1e3)
     roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=_traffic_from_profiles(dom),
+                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=_traffic_from_profiles(dom) if (args.workload == "cfg3" and world == 1) else None,
                     avg_launch_ms=round(dom_ms, 4), algorithmic_bytes_per_launch=int(bytes_per_launch),
                     step_algorithmic_bytes=int(sum(alg.values())),
                     step_frac=round(sum(alg.values()) / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 5),
@@ -277,7 +277,8 @@ def _train_loop(workload, iters, dev):
 
 
 def _traffic_from_profiles(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json: FETCH_SIZE x2 +
+    WRITE_SIZE, made by profiles/pmc_to_traffic.py for the default cfg3 single-GPU run), or None."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(path):
         try:

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs as
+MI355X_MICROARCH.md "HBM" prescribes) into profiles/traffic.json = HBM bytes per launch per kernel,
+the number bench.py reports as roofline.traffic.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline
+    python3 profiles/pmc_to_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> profiles
+
+Units and corrections (guide, "HBM [CDNA4]"): both counters are in KiB-like units of 1024 B as rocprofv3
+reports them; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is DOUBLED; WRITE_SIZE is exact for
+wide streaming stores.  The first launches of every kernel (warm-up, cold caches) are dropped.
+"""
+import csv
+import json
+import os
+import sys
+from collections import defaultdict
+
+# kernel-name prefix (demangled, as rocprofv3 prints it) -> key used in bench.py's "kernels" table
+NAMES = {
+    "gsr::k_render_bwd": "render_bwd", "gsr::k_render_fwd": "render_fwd", "void gsr::k_geom_bwd<": "geom_bwd",
+    "void gsr::k_geom_bwd_sparse<": "geom_bwd", "void gsr::k_preprocess<": "preprocess",
+    "void gsr::k_reduce_rows<": "reduce_rows", "gsr::k_loss_fwd": "loss_fwd", "gsr::k_loss_bwd": "loss_bwd",
+    "gsr::k_emit": "emit", "gsr::k_count_open": "count_open", "gsr::k_ranges": "ranges",
+}
+SKIP_FIRST = 3
+
+
+def per_launch(path, counter):
+    by = defaultdict(list)
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            for prefix, key in NAMES.items():
+                if row["Kernel_Name"].startswith(prefix):
+                    by[key].append(float(row["Counter_Value"]) * 1024.0)
+                    break
+    return {k: v[SKIP_FIRST:] for k, v in by.items() if len(v) > SKIP_FIRST}
+
+
+def main():
+    fetch_csv, write_csv, outdir = sys.argv[1:4]
+    fetch, write = per_launch(fetch_csv, "FETCH_SIZE"), per_launch(write_csv, "WRITE_SIZE")
+    detail, traffic = {}, {}
+    for k in sorted(set(fetch) & set(write)):
+        fb = 2.0 * sum(fetch[k]) / len(fetch[k])          # gfx950 correction: x2
+        wb = sum(write[k]) / len(write[k])
+        detail[k] = dict(fetch_bytes_per_launch=int(fb), write_bytes_per_launch=int(wb), hbm_bytes_per_launch=int(fb + wb),
+                         launches_sampled=min(len(fetch[k]), len(write[k])))
+        traffic[k] = int(fb + wb)
+    with open(os.path.join(outdir, "traffic.json"), "w") as f:
+        json.dump(traffic, f, indent=1)
+    with open(os.path.join(outdir, "r01_pmc_traffic_detail.json"), "w") as f:
+        json.dump(detail, f, indent=1)
+    print(json.dumps(detail, indent=1))
+
+
+if __name__ == "__main__":
+    main()

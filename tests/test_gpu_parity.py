@@ -277,6 +277,22 @@ def test_empty_and_degenerate_inputs():
     assert torch.all(means2D.grad == 0)
 
 
+def test_image_with_more_than_65536_tiles():
+    """4352 x 4112 pixels = 272 x 257 = 69 904 tiles: tile ids need 17 bits, so the per-chunk tile sort takes
+    3 radix passes instead of 2.  Forward + backward against the fp64 oracle, tolerances as everywhere; the
+    fragile-decision band is 5e-5 instead of 2e-6 because the scene's nearest splats are ~3000 px wide and the
+    quadratic form's binary32 rounding grows with the pixel offsets (the oracle's own binary32 instantiation
+    differs from binary64 on 19 pixels at 2e-6, on none at 1e-5)."""
+    W, H = 4352, 4112
+    kw = _fixture_kwargs(dict(P=3000, W=W, H=H, D=1, seed=211))
+    fr64 = oracle.rasterize(dtype=np.float64, fragile_eps=5e-5, parallel=True, **kw)
+    assert fr64.Gx * fr64.Gy > 65536
+    gimg = S.make_grad_image(W, H, 9).numpy()
+    color, radii, grads = _run_gpu(kw, gimg)
+    _check_forward(kw, fr64, color, radii)
+    _check_grads(fr64, fr64.backward(gimg), grads, ["means3D", "means2D", "opacities", "shs", "scales", "rotations"])
+
+
 def test_api_contract():
     from diff_gaussian_rasterization import GaussianRasterizer
     kw = _fixture_kwargs(dict(P=2048, W=128, H=128, D=3, seed=105))
