@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 2
+#define GSR_VERSION 3
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -116,10 +116,16 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
 int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *geom_ws, void *binning_ws,
                        void *image_ws, gsr_frame_plan *plan_host, float *out_color, void *stream);
 
-/* First half of `_C.rasterize_gaussians_backward`: reverse blend of the slab's tiles and the
+/* Size of the backward-only scratch: one 48-byte gradient row per instance the forward EMITTED
+ * (plan_host->instances_emitted, a few per cent of num_rendered; the emission bound of the chunks that ran
+ * when the forward went through its last chunk), so it is allocated when the backward runs and freed right
+ * after it. */
+int gsr_backward_rows_size(const gsr_frame_desc *desc, const gsr_frame_plan *plan_host, size_t *rows_bytes);
+
+/* First half of `_C.rasterize_gaussians_backward`: reverse blend of the slab's tiles into rows_ws and the
  * deterministic per-Gaussian reduction -> screen_grads[P, GSR_SCREEN_GRAD_STRIDE]. */
 int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const void *geom_ws, void *binning_ws,
-                        const void *image_ws, const gsr_frame_plan *plan_host, const float *dL_dcolor,
+                        const void *image_ws, void *rows_ws, const gsr_frame_plan *plan_host, const float *dL_dcolor,
                         float *screen_grads, void *stream);
 
 /* Second half of `_C.rasterize_gaussians_backward`: per-Gaussian backward (2D covariance, projection,

@@ -224,14 +224,31 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *
     return GSR_OK;
 }
 
+int gsr_backward_rows_size(const gsr_frame_desc *desc, const gsr_frame_plan *plan, size_t *rows_bytes)
+{
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!plan || !rows_bytes) { set_error("gsr_backward_rows_size: NULL argument"); return GSR_ERR_INVALID_ARGUMENT; }
+    // exact when the forward stopped early (the count was read back with the open-tile count); when the LAST
+    // chunk ran its count stayed on the device and the bound is what the chunks that ran could have emitted
+    long long n = plan->instances_emitted;
+    if (n < 0) {
+        n = 0;
+        for (int c = 0; c < plan->chunks_run && c < GSR_MAX_CHUNKS; ++c) n += plan->chunk_instances_max[c];
+    }
+    if (n < 1) n = 1;
+    *rows_bytes = align_up((size_t)n * kRowFloats * sizeof(float));
+    return GSR_OK;
+}
+
 int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const void *geom_ws, void *binning_ws,
-                        const void *image_ws, const gsr_frame_plan *plan, const float *dL_dcolor, float *screen_grads,
-                        void *stream)
+                        const void *image_ws, void *rows_ws, const gsr_frame_plan *plan, const float *dL_dcolor,
+                        float *screen_grads, void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
     if (!cam || !cam->bg || !dL_dcolor || !plan || (desc->P > 0 && (!screen_grads || !geom_ws)) || !image_ws ||
-        (plan->num_rendered > 0 && !binning_ws)) {
+        (plan->num_rendered > 0 && (!binning_ws || !rows_ws))) {
         set_error("gsr_backward_render: NULL argument");
         return GSR_ERR_INVALID_ARGUMENT;
     }
@@ -242,6 +259,7 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
     ImageWS iw = carve_image(const_cast<void *>(image_ws), f);
     BinningWS bw = carve_binning(binning_ws, plan->num_rendered);
+    bw.grad_rows = (float *)rows_ws;
     if (plan->num_rendered > 0 &&
         (rc = launch_render_bwd(f, *cam, plan->chunks_run, plan->sort_result, gw, bw, iw, dL_dcolor, dbg, s)))
         return rc;

@@ -81,7 +81,7 @@ BinningWS carve_binning(void *base, int64_t R)
     for (int i = 0; i < 2; ++i) { w.vals[i] = (uint32_t *)(b + o); o += align_up(Rn * 4); }
     w.inst_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
     w.sorted_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
-    w.grad_rows = (float *)(b + o); o += align_up(Rn * kRowFloats * 4);
+    w.grad_rows = nullptr;                          // backward-only, sized from instances_emitted: gsr_backward_rows_size
     w.total = o;
     return w;
 }

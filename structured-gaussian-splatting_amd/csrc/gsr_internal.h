@@ -104,7 +104,8 @@ struct BinningWS {              // O(R): the reference's binningBuffer
     uint32_t *vals[2];          // [R] x2 payload = instance slot (absolute index in emission order)
     uint32_t *inst_gid;         // [R] slot -> Gaussian
     uint32_t *sorted_gid;       // [R] sorted position -> Gaussian
-    float *grad_rows;           // [R, kRowFloats] per-instance screen-space gradient rows (backward)
+    float *grad_rows;           // [instances emitted, kRowFloats] per-instance screen-space gradient rows: the caller's
+                                // backward-time allocation (gsr_backward_rows_size), not part of the carved block
     size_t total;
 };
 constexpr int kLastShift = 26;  // last_enc = (chunk + 1) << kLastShift | position

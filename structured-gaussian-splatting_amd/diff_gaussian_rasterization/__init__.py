@@ -114,7 +114,10 @@ def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.T
     if grad_color is None:
         return screen.zero_()[:P]
     with torch.cuda.device(fr.device):
-        N.backward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, grad_color, screen, fr.device)
+        # one 48-B gradient row per EMITTED instance: backward-only scratch, returned to the allocator on exit
+        rows = torch.empty(N.backward_rows_size(fr.desc, fr.plan), dtype=torch.uint8, device=fr.device)
+        N.backward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, rows, fr.plan, grad_color, screen,
+                          fr.device)
     return screen[:P]
 
 

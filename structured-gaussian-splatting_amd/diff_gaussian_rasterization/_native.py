@@ -58,7 +58,7 @@ class DebugViews(C.Structure):
 
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
-           "gsr_forward_render", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
+           "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward",
            "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step")
 
@@ -144,9 +144,16 @@ def forward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, plan: Frame
                                      C.byref(plan), _ptr(out_color), _stream(device)), "gsr_forward_render")
 
 
-def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, plan: FramePlan, dL_dcolor, screen_grads, device):
+def backward_rows_size(desc: FrameDesc, plan: FramePlan) -> int:
+    b = C.c_size_t(0)
+    _check(load().gsr_backward_rows_size(C.byref(desc), C.byref(plan), C.byref(b)), "gsr_backward_rows_size")
+    return b.value
+
+
+def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, rows_ws, plan: FramePlan, dL_dcolor, screen_grads,
+                    device):
     _check(load().gsr_backward_render(C.byref(desc), C.byref(cam), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws),
-                                      C.byref(plan), _ptr(dL_dcolor), _ptr(screen_grads), _stream(device)),
+                                      _ptr(rows_ws), C.byref(plan), _ptr(dL_dcolor), _ptr(screen_grads), _stream(device)),
            "gsr_backward_render")
 
 

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(native):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gsrast.h but not exported"
     assert set(native.EXPORTS) == declared
-    assert lib.gsr_version() == 2
+    assert lib.gsr_version() == 3
 
 
 def test_argument_validation_without_gpu(native):
@@ -40,7 +40,12 @@ def test_argument_validation_without_gpu(native):
     ok = native.make_desc(1000, 3, 16, 100, 60, 0.5, 0.5, 1.0, False, False)
     gb, ib = native.workspace_sizes(ok)
     assert gb >= 1000 * 57 and ib >= 100 * 60 * 8 + 7 * 4 * 8
-    assert native.binning_size(ok, 5000) >= 5000 * (4 * 6 + 48)
+    assert 5000 * 4 * 6 <= native.binning_size(ok, 5000) < 5000 * 4 * 6 + 4096
+    # backward-only gradient rows: 48 B per EMITTED instance; the emission bound when the count stayed on the device
+    plan = native.FramePlan(); plan.instances_emitted = 1234
+    assert 1234 * 48 <= native.backward_rows_size(ok, plan) < 1234 * 48 + 512
+    plan.instances_emitted = -1; plan.chunks_run = 2; plan.chunk_instances_max[0] = 1000; plan.chunk_instances_max[1] = 500
+    assert 1500 * 48 <= native.backward_rows_size(ok, plan) < 1500 * 48 + 512
     with pytest.raises(native.GsrError, match="sh_coeffs"):
         native.workspace_sizes(native.make_desc(10, 1, 99, 64, 64, 0.5, 0.5, 1.0, False, False))
     # exactly-one-of rules are enforced at the ABI too (NULL device pointers are never dereferenced here)
