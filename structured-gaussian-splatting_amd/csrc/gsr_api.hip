@@ -162,6 +162,11 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     Ctrl h;
     GSR_HIP_CHECK(hipMemcpyAsync(&h, gw.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
     GSR_HIP_CHECK(hipStreamSynchronize(s));
+    if (h.overflow) {
+        set_error("the frame's tile instances (sum of tiles touched over %d visible Gaussians) exceed 2^32 - 1: "
+                  "split the frame into tile-row slabs (gsr_frame_desc.tile_row_begin/end)", (int)h.V);
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
     plan->num_rendered = (int64_t)h.R_total;
     plan->num_visible = (int32_t)h.V;
     plan->num_chunks = h.num_chunks > 0 ? (int32_t)h.num_chunks : 1;

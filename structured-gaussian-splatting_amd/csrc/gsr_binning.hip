@@ -115,7 +115,7 @@ int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
         GSR_LAUNCH_CHECK("gather_tiles", debug, s);
     }
     return launch_scan_inclusive(ws.tiles_sorted, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, nullptr, nullptr, "scan_tiles",
-                                 debug, s);
+                                 debug, s, &ws.ctrl->overflow);
 }
 
 // ---- chunk plan (one block of 9 waves): wave 0 finds V (first rank whose key is 0xFFFFFFFF), wave 1+c the end

@@ -73,6 +73,7 @@ struct Ctrl {                   // small device-side control block of one frame
     uint32_t chunk_full[GSR_MAX_CHUNKS];       // instances of the chunk if every tile were open
     uint32_t chunk_R[GSR_MAX_CHUNKS];          // instances actually emitted
     uint32_t chunk_base[GSR_MAX_CHUNKS + 1];   // first absolute instance index of the chunk
+    uint32_t overflow;                         // 1 = the sum of tiles touched does not fit 32 bits
 };
 struct GeomWS {                 // O(P): the reference's geomBuffer
     float4 *records;            // [P,3]  Splat records, by Gaussian
@@ -118,7 +119,7 @@ BinningWS carve_binning(void *base, int64_t R);
 
 // ---- primitives (gsr_sort.hip)
 int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
-                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s);
+                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow = nullptr);
 template <typename K>
 int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
                       const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,

@@ -65,17 +65,32 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_local(const uint32_t *__res
 
 // exclusive scan of the block sums, any count, one block
 __global__ __launch_bounds__(kScanBlock) void k_scan_tops(uint32_t *__restrict__ block_sums, int nb, uint32_t *__restrict__ grand_total,
-                                                          const uint32_t *__restrict__ acc_in, uint32_t *__restrict__ acc_out)
+                                                          const uint32_t *__restrict__ acc_in, uint32_t *__restrict__ acc_out,
+                                                          uint32_t *__restrict__ overflow)
 {
     __shared__ uint32_t sh_wave[kScanBlock / kWave];
+    __shared__ unsigned long long sh_wide[kScanBlock / kWave];
     uint32_t carry = 0;
+    unsigned long long wide = 0;                               // the same sum in 64 bits, to detect wrap-around
     for (int base = 0; base < nb; base += kScanBlock) {
         const int i = base + threadIdx.x;
         const uint32_t v = i < nb ? block_sums[i] : 0u;
+        wide += v;
         uint32_t total;
         const uint32_t inc = block_incl_scan(v, sh_wave, &total);
         if (i < nb) block_sums[i] = carry + inc - v;
         carry += total;
+    }
+    if (overflow) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) wide += __shfl_xor(wide, off);
+        if ((threadIdx.x & 63) == 0) sh_wide[threadIdx.x >> 6] = wide;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (int i = 0; i < kScanBlock / kWave; ++i) t += sh_wide[i];
+            *overflow = t > 0xFFFFFFFFull ? 1u : 0u;
+        }
     }
     if (threadIdx.x == 0) {
         if (grand_total) *grand_total = carry;
@@ -96,9 +111,10 @@ size_t scan_temp_bytes(int n) { return align_up((size_t)((n + kScanTile - 1) / k
 
 // out[i] = in[0] + ... + in[i]; optional *grand_total (device) = sum of all.
 int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
-                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s)
+                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow)
 {
     if (n <= 0) {
+        if (overflow) GSR_HIP_CHECK(hipMemsetAsync(overflow, 0, 4, s));
         if (grand_total) GSR_HIP_CHECK(hipMemsetAsync(grand_total, 0, 4, s));
         if (acc_out && acc_in) GSR_HIP_CHECK(hipMemcpyAsync(acc_out, acc_in, 4, hipMemcpyDeviceToDevice, s));
         return GSR_OK;
@@ -107,7 +123,7 @@ int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, 
     const int nb = (n + kScanTile - 1) / kScanTile;
     uint32_t *sums = (uint32_t *)temp;
     hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kScanBlock), 0, s, in, out, sums, n);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(kScanBlock), 0, s, sums, nb, grand_total, acc_in, acc_out);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(kScanBlock), 0, s, sums, nb, grand_total, acc_in, acc_out, overflow);
     if (nb > 1) hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanBlock), 0, s, out, sums, n);
     GSR_LAUNCH_CHECK(name, debug, s);
     return GSR_OK;

@@ -620,3 +620,61 @@ def test_fused_adam_matches_torch_adam():
         assert (a - b).detach().abs().max() <= 2e-6 * max(1.0, float(a.detach().abs().max()))
         assert (ref.state[a]["exp_avg_sq"] - fus.state[b]["exp_avg_sq"]).abs().max() <= 1e-6
     ref.load_state_dict(fus.state_dict())                              # same layout
+
+
+def test_integration_md_binding_example_runs():
+    """INTEGRATION.md section 2 shows the ctypes binding a maintainer of the upstream extension would write against
+    libgsrast.so.  The code block is executed as written (only the library path is substituted) and must give
+    bitwise the package's own result: the document cannot drift from the ABI."""
+    import re
+    from diff_gaussian_rasterization import GaussianRasterizer, _native
+    text = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, re.S).group(1).replace('"libgsrast.so"', repr(_native.lib_path()))
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    kw = _fixture_kwargs(dict(P=5000, W=200, H=136, D=2, seed=77, bg=(0.2, 0.1, 0.3)))
+    rs, inp = _settings(kw), _inputs(kw, True)
+    P, M = inp["means3D"].shape[0], inp["shs"].shape[1]
+    gimg = S.make_grad_image(200, 136, 4).to(DEV)
+    means2D = torch.zeros(P, 3, device=DEV, requires_grad=True)
+    color, radii = GaussianRasterizer(rs)(means2D=means2D, **inp)
+    color.backward(gimg)
+    e = torch.empty(0, device=DEV)
+    d = {k: v.detach() for k, v in inp.items()}
+    R, color2, radii2, saved = ns["rasterize_gaussians"](
+        rs.bg, d["means3D"], e, d["opacities"], d["scales"], d["rotations"], rs.scale_modifier, e, rs.viewmatrix,
+        rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, d["shs"], rs.sh_degree, rs.campos, False, False)
+    assert R > 0 and torch.equal(color2, color.detach()) and torch.equal(radii2, radii)
+    out = ns["rasterize_gaussians_backward"](saved, gimg, P, M)
+    torch.cuda.synchronize()
+    for k in ("means3D", "shs", "opacities", "scales", "rotations"):
+        assert torch.equal(out[k], inp[k].grad), k
+    assert torch.equal(out["means2D"], means2D.grad)
+
+
+def test_more_than_2_pow_32_tile_instances_is_an_error_not_a_wrap():
+    """70 000 screen-filling Gaussians over 65 536 tiles: the sum of tiles touched (4.6e9) does not fit the 32-bit
+    instance index.  The frame is refused with a message (the sum is also formed in 64 bits on the device);
+    rendering it as two tile-row slabs, as the message says, works."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _native
+    from diff_gaussian_rasterization import rasterize_forward
+    P, W, H = 70_000, 4096, 4096
+    cam = S.make_camera(W, H)
+    g = torch.Generator().manual_seed(5)
+    means = torch.cat([(torch.rand(P, 2, generator=g) - 0.5) * 0.1, torch.full((P, 1), 1.0)], 1)
+    scene = S.make_scene(P, W, H, 0, 5)
+    kw = raster_kwargs(scene, cam)
+    kw["means3D"] = means.numpy()
+    kw["scales"] = np.full((P, 3), 50.0, np.float32)
+    kw["opacities"] = np.full((P, 1), 0.9, np.float32)
+    rs, inp = _settings(kw), _inputs(kw, False)
+    with pytest.raises(_native.GsrError, match="exceed 2\\^32"):
+        GaussianRasterizer(rs)(means2D=torch.zeros(P, 3, device=DEV), **inp)
+    # a slab of 16 of the 256 tile rows fits (2.9e8 instances of upper bound, almost none emitted: the tiles saturate
+    # within the first few splats)
+    color, radii, fr = rasterize_forward(inp["means3D"], inp["shs"], None, inp["opacities"], inp["scales"], inp["rotations"],
+                                         None, rs, tile_rows=(0, 16))
+    torch.cuda.synchronize()
+    assert fr.R == P * 16 * 256 and int((radii > 0).sum()) == P
+    assert fr.plan.chunks_run == 1 and 0 <= fr.plan.instances_emitted < fr.R // 100
+    assert torch.isfinite(color).all() and float(color[:, :256].abs().sum()) > 0 and float(color[:, 256:].abs().sum()) == 0
