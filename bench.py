@@ -134,6 +134,24 @@ def main():
     elapsed_profiled = time.perf_counter() - t1
     prof = N.profile_read()
     N.profile_enable(False)
+    # (3) extension, reported beside `value`, never as it: the same K steps with the activations of the parameter
+    # store (exp / sigmoid / normalize / cat and their backward) fused into the HIP kernels
+    # (pipe.fused_activations -> GaussianRasterizer.forward_raw) instead of running as ~30 torch kernels
+    fused = None
+    if world == 1:
+        pipe.fused_activations = True
+        for _ in range(max(args.warmup, 1)):
+            step()
+        sync()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        el = time.perf_counter() - t2
+        pipe.fused_activations = False
+        fused = {"value": round(args.steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / args.steps, 4),
+                 "what": "same step, activations fused into preprocess / geometry-backward kernels (extension beyond the "
+                         "reference API: render(..., pipe.fused_activations=True)); same image and parameter gradients"}
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,7 +193,8 @@ def main():
 
     train_loop = None
     if world == 1 and args.train_loop > 0:
-        train_loop = _train_loop(args.workload, args.train_loop, dev)
+        train_loop = _train_loop(args.workload, args.train_loop, dev, False)
+        train_loop["fused_activations"] = _train_loop(args.workload, args.train_loop, dev, True)
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
@@ -198,6 +217,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
     }
+    if fused is not None:
+        line["fused_activations"] = fused
     if train_loop is not None:
         line["train_loop"] = train_loop
     print(json.dumps(line))
@@ -240,7 +261,7 @@ def _frame_stats(model, cam, bg, pipe):
                 pairs_bwd=int(ncontrib.sum()))
 
 
-def _train_loop(workload, iters, dev):
+def _train_loop(workload, iters, dev, fused):
     """BASELINE configs[2] taken literally: the full train.py loop (LR schedule, render, loss, backward,
     densification statistics, densify/prune every 100 iterations, Adam) starting from the workload's cloud, with
     target views rendered from a second cloud (seed 30) on 8 cameras of a small arc."""
@@ -264,11 +285,13 @@ def _train_loop(workload, iters, dev):
     opt = replace(OptimizationDefaults(), densify_from_iter=0)
     gm.training_setup(opt)
     warm = min(20, iters // 4)
-    train(gm, cams, targets, opt, Pipe(), bg, iterations=warm, scene_extent=6.0)
+    pipe = Pipe()
+    pipe.fused_activations = bool(fused)
+    train(gm, cams, targets, opt, pipe, bg, iterations=warm, scene_extent=6.0)
     torch.cuda.synchronize(dev)
     n0 = gm._xyz.shape[0]
     t0 = time.perf_counter()
-    train(gm, cams, targets, opt, Pipe(), bg, iterations=warm + iters, first_iter=warm + 1, scene_extent=6.0)
+    train(gm, cams, targets, opt, pipe, bg, iterations=warm + iters, first_iter=warm + 1, scene_extent=6.0)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     return {"iterations": iters, "its_per_s": round(iters / dt, 2), "ms_per_it": round(1e3 * dt / iters, 3),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 3
+#define GSR_VERSION 4
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -79,6 +79,16 @@ typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettin
 
 typedef struct gsr_gaussians {   /* arguments of GaussianRasterizer.forward (device) */
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    /* SURVEY 8a row a14, optional: raw != 0 hands over the optimizer's RAW parameters of the reference's
+     * GaussianModel and the activations of scene/gaussian_model.py:47-60,108-127 run inside the per-Gaussian
+     * kernels instead of as ~30 torch kernels around them:
+     *   opacities = _opacity logits        -> sigmoid        scales    = _scaling log-scales -> exp
+     *   rotations = _rotation quaternions  -> normalize      shs       = _features_dc   [P,1,3]
+     *   shs_rest  = _features_rest [P, sh_coeffs - 1, 3] (the torch.cat of get_features); NULL iff sh_coeffs == 1
+     * colors_precomp and cov3D_precomp must be NULL.  The backward then returns gradients w.r.t. the raw
+     * tensors (chain rule through the activations fused into gsr_backward_geom). */
+    const float *shs_rest;
+    int32_t raw;
 } gsr_gaussians;
 
 typedef struct gsr_grads {       /* outputs of the backward; any may be NULL (not wanted) */
@@ -90,6 +100,7 @@ typedef struct gsr_grads {       /* outputs of the backward; any may be NULL (no
     float *scales;         /* [P,3]   */
     float *rotations;      /* [P,4]   */
     float *cov3D_precomp;  /* [P,6]   */
+    float *shs_rest;       /* [P,M-1,3] raw mode only (then shs is [P,1,3]) */
 } gsr_grads;
 
 int gsr_version(void);

@@ -11,12 +11,68 @@ namespace gsr {
 
 constexpr int kGeomBlock = 256;
 
-template <int DEG>
+// One Gaussian's inputs in registers.  RAW: the tensors are the optimizer's raw parameters and
+// the activations (exp / normalize / sigmoid, cat of the SH features) happen here, in registers.
+template <int DEG, bool RAW>
+struct GaussIn {
+    float p[3], sc[3], q[4], cv[6], opacity;
+    float shl[RAW ? 3 * (DEG + 1) * (DEG + 1) : 1];
+    const float *sh;          // this Gaussian's [K,3] coefficients as preprocess_one / geom_backward_one read them
+    RawAct act;
+};
+
+template <int DEG, bool RAW>
+__device__ __forceinline__ void load_gaussian(int i, int M, const float *__restrict__ means, const float *__restrict__ scales,
+                                              const float *__restrict__ rots, const float *__restrict__ covpre,
+                                              const float *__restrict__ opac, const float *__restrict__ shs,
+                                              const float *__restrict__ shs_rest, bool with_sh, GaussIn<DEG, RAW> &in)
+{
+    in.p[0] = means[3 * i]; in.p[1] = means[3 * i + 1]; in.p[2] = means[3 * i + 2];
+    in.sc[0] = in.sc[1] = in.sc[2] = 0.f;
+    in.q[0] = 1.f; in.q[1] = in.q[2] = in.q[3] = 0.f;
+    if constexpr (RAW) {
+        const float ls[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+        const float4 qq = reinterpret_cast<const float4 *>(rots)[i];
+        const float rq[4] = {qq.x, qq.y, qq.z, qq.w};
+        activate_raw(ls, rq, opac[i], in.act);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in.sc[k] = in.act.scale[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in.q[k] = in.act.q[k];
+        in.opacity = in.act.opacity;
+        constexpr int K = (DEG + 1) * (DEG + 1);
+        if (with_sh) {                       // culled Gaussians never read their coefficients
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) in.shl[ch] = shs[3 * (size_t)i + ch];
+            const float *rest = shs_rest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+            for (int k = 3; k < 3 * K; ++k) in.shl[k] = rest[k - 3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3 * K; ++k) in.shl[k] = 0.f;
+        }
+        in.sh = in.shl;
+    } else {
+        if (covpre) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) in.cv[k] = covpre[6 * (size_t)i + k];
+        } else {
+            in.sc[0] = scales[3 * i]; in.sc[1] = scales[3 * i + 1]; in.sc[2] = scales[3 * i + 2];
+            const float4 qq = reinterpret_cast<const float4 *>(rots)[i];
+            in.q[0] = qq.x; in.q[1] = qq.y; in.q[2] = qq.z; in.q[3] = qq.w;
+        }
+        in.opacity = opac ? opac[i] : 0.f;
+        in.sh = shs ? shs + (size_t)i * M * 3 : nullptr;
+    }
+}
+
+template <int DEG, bool RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float *__restrict__ view,
                                                            const float *__restrict__ proj, const float *__restrict__ campos,
                                                            const float *__restrict__ means, const float *__restrict__ scales,
                                                            const float *__restrict__ rots, const float *__restrict__ covpre,
                                                            const float *__restrict__ opac, const float *__restrict__ shs,
+                                                           const float *__restrict__ shs_rest,
                                                            const float *__restrict__ colpre, float4 *__restrict__ records,
                                                            uint32_t *__restrict__ tiles, uint8_t *__restrict__ clamped,
                                                            int32_t *__restrict__ radii, uint32_t *__restrict__ sort_keys,
@@ -28,19 +84,12 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
-    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, cv[6];
-    if (covpre) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cv[k] = covpre[6 * (size_t)i + k];
-    } else {
-        sc[0] = scales[3 * i]; sc[1] = scales[3 * i + 1]; sc[2] = scales[3 * i + 2];
-        const float4 qq = reinterpret_cast<const float4 *>(rots)[i];
-        q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-    }
+    GaussIn<DEG, RAW> in;
+    const float p0[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    load_gaussian<DEG, RAW>(i, f.M, means, scales, rots, covpre, opac, shs, shs_rest, in_frustum(p0, V), in);
     PreOut o;
-    preprocess_one<DEG>(f, V, PV, cp, p, sc, q, covpre ? cv : nullptr, opac[i], shs ? shs + (size_t)i * f.M * 3 : nullptr,
-                   colpre ? colpre + 3 * (size_t)i : nullptr, o);
+    preprocess_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.opacity, in.sh,
+                        (!RAW && colpre) ? colpre + 3 * (size_t)i : nullptr, o);
     radii[i] = o.radius;
     tiles[i] = o.tiles;
     clamped[i] = (uint8_t)o.clamped;
@@ -60,16 +109,25 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
     if (f.P == 0) return GSR_OK;
     const int grid = (f.P + kGeomBlock - 1) / kGeomBlock;
     ProfileScope prof("preprocess", s);
-#define GSR_PRE(DEG)                                                                                              \
-    hipLaunchKernelGGL(k_preprocess<DEG>, dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
-                       cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs,         \
-                       g.colors_precomp, ws.records, ws.tiles_touched, ws.clamped, radii, ws.sort_keys[0],  \
+#define GSR_PRE(DEG, RAW)                                                                                           \
+    hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
+                       cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs, g.shs_rest,   \
+                       g.colors_precomp, ws.records, ws.tiles_touched, ws.clamped, radii, ws.sort_keys[0],              \
                        ws.sort_vals[0])
-    switch (g.shs ? f.D : 0) {
-        case 0: GSR_PRE(0); break;
-        case 1: GSR_PRE(1); break;
-        case 2: GSR_PRE(2); break;
-        default: GSR_PRE(3); break;
+    if (g.raw) {
+        switch (f.D) {
+            case 0: GSR_PRE(0, true); break;
+            case 1: GSR_PRE(1, true); break;
+            case 2: GSR_PRE(2, true); break;
+            default: GSR_PRE(3, true); break;
+        }
+    } else {
+        switch (g.shs ? f.D : 0) {
+            case 0: GSR_PRE(0, false); break;
+            case 1: GSR_PRE(1, false); break;
+            case 2: GSR_PRE(2, false); break;
+            default: GSR_PRE(3, false); break;
+        }
     }
 #undef GSR_PRE
     GSR_LAUNCH_CHECK("preprocess", debug, s);
@@ -77,12 +135,13 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 }
 
 // ---- K8 + K9: dL/d(screen-space quantities) -> dL/d(inputs) for Gaussians [g0, g1).
-template <int DEG>
+template <int DEG, bool RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g1, const float *__restrict__ view,
                                                          const float *__restrict__ proj, const float *__restrict__ campos,
                                                          const float *__restrict__ means, const float *__restrict__ scales,
                                                          const float *__restrict__ rots, const float *__restrict__ covpre,
-                                                         const float *__restrict__ shs, int has_colpre,
+                                                         const float *__restrict__ opac, const float *__restrict__ shs,
+                                                         const float *__restrict__ shs_rest, int has_colpre,
                                                          const int32_t *__restrict__ radii, const uint8_t *__restrict__ clamped,
                                                          const float4 *__restrict__ screen, gsr_grads out)
 {
@@ -116,19 +175,12 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
 #pragma unroll
         for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
         cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
-        const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, cv[6];
-        if (covpre) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cv[k] = covpre[6 * (size_t)i + k];
-        } else {
-            sc[0] = scales[3 * i]; sc[1] = scales[3 * i + 1]; sc[2] = scales[3 * i + 2];
-            const float4 qq = reinterpret_cast<const float4 *>(rots)[i];
-            q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-        }
+        GaussIn<DEG, RAW> in;
+        load_gaussian<DEG, RAW>(i, M, means, scales, rots, covpre, opac, shs, shs_rest, true, in);
         const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
-        geom_backward_one<DEG>(f, V, PV, cp, p, sc, q, covpre ? cv : nullptr, shs ? shs + (size_t)i * M * 3 : nullptr,
-                          has_colpre != 0, clamped[i], sg, g, (shs && out.shs) ? dsh : nullptr);
+        geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh, has_colpre != 0,
+                               clamped[i], sg, g, (shs && (out.shs || (RAW && out.shs_rest))) ? dsh : nullptr);
+        if constexpr (RAW) activate_raw_backward(in.act, g);
     }
     if (!in_range) { /* lanes past the end only help with the cooperative SH store below */ }
     else {
@@ -145,15 +197,23 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
         for (int k = 0; k < 6; ++k) out.cov3D_precomp[6 * (size_t)i + k] = g.dcov[k];
     }
     }
-    if (out.shs && shs) {
-        // dL/dsh rows are 12*M bytes per Gaussian: a wave's 64 rows form one contiguous run, written with
+    if constexpr (RAW) {
+        if (in_range && out.shs) {
+            out.shs[3 * (size_t)i] = live ? dsh[0] : 0.f; out.shs[3 * (size_t)i + 1] = live ? dsh[1] : 0.f;
+            out.shs[3 * (size_t)i + 2] = live ? dsh[2] : 0.f;
+        }
+    }
+    float *sh_out = RAW ? out.shs_rest : out.shs;
+    const int row = RAW ? 3 * (M - 1) : 3 * M;                    // floats per Gaussian in sh_out
+    constexpr int off = RAW ? 3 : 0;                              // first dsh entry that belongs to sh_out
+    if (sh_out && shs && row > 0) {
+        // dL/dsh rows are `row` floats per Gaussian: a wave's 64 rows form one contiguous run, written with
         // lane-contiguous stores.  Fast path (no live Gaussian in the wave): zeros straight from registers.
-        // Otherwise the rows go through LDS (row stride 3M+1 dwords: conflict-free transposition).
+        // Otherwise the rows go through LDS (row stride row+1 dwords: conflict-free transposition).
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const int row = 3 * M;                                    // floats per Gaussian
         const int wave_first = i - lane;                           // first Gaussian of this wave
         const int n_rows = min(64, g1 - wave_first);
-        float *dst = out.shs + (size_t)wave_first * row;
+        float *dst = sh_out + (size_t)wave_first * row;
         const int total = n_rows * row;
         if (__ballot(live) == 0ull) {
             for (int e = lane; e < total; e += 64) dst[e] = 0.f;
@@ -161,8 +221,8 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
             float *stage = sh_stage + w * (64 * 49);
             const int nlive = live ? 3 * K : 0;
 #pragma unroll
-            for (int k = 0; k < 48; ++k)
-                if (k < row) stage[lane * (row + 1) + k] = k < nlive ? dsh[k] : 0.f;
+            for (int k = 0; k < 48 - off; ++k)
+                if (k < row) stage[lane * (row + 1) + k] = (k + off) < nlive ? dsh[k + off] : 0.f;
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             for (int e = lane; e < total; e += 64) dst[e] = stage[(e / row) * (row + 1) + e % row];
@@ -173,12 +233,13 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
 // ---- sparse variant for depth-complex frames: every output was zero-filled by memset; only the Gaussians of the
 // binned depth prefix (rank < n_ranks) can have a non-zero screen-space gradient.  One thread per rank, rows
 // written individually (they are few).
-template <int DEG>
+template <int DEG, bool RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_ranks, const uint32_t *__restrict__ order,
                                                                 const float *__restrict__ view, const float *__restrict__ proj,
                                                                 const float *__restrict__ campos, const float *__restrict__ means,
                                                                 const float *__restrict__ scales, const float *__restrict__ rots,
-                                                                const float *__restrict__ covpre, const float *__restrict__ shs,
+                                                                const float *__restrict__ covpre, const float *__restrict__ opac,
+                                                                const float *__restrict__ shs, const float *__restrict__ shs_rest,
                                                                 int has_colpre, const int32_t *__restrict__ radii,
                                                                 const uint8_t *__restrict__ clamped,
                                                                 const float4 *__restrict__ screen, gsr_grads out)
@@ -196,21 +257,14 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
 #pragma unroll
     for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
-    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, cv[6];
-    if (covpre) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) cv[k] = covpre[6 * (size_t)i + k];
-    } else {
-        sc[0] = scales[3 * i]; sc[1] = scales[3 * i + 1]; sc[2] = scales[3 * i + 2];
-        const float4 qq = reinterpret_cast<const float4 *>(rots)[i];
-        q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
-    }
+    GaussIn<DEG, RAW> in;
+    load_gaussian<DEG, RAW>(i, M, means, scales, rots, covpre, opac, shs, shs_rest, true, in);
     const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
     GeomGrad g;
     float dsh[48];
-    geom_backward_one<DEG>(f, V, PV, cp, p, sc, q, covpre ? cv : nullptr, shs ? shs + (size_t)i * M * 3 : nullptr, has_colpre != 0,
-                           clamped[i], sg, g, (shs && out.shs) ? dsh : nullptr);
+    geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh, has_colpre != 0, clamped[i],
+                           sg, g, (shs && (out.shs || (RAW && out.shs_rest))) ? dsh : nullptr);
+    if constexpr (RAW) activate_raw_backward(in.act, g);
     if (out.means3D) { out.means3D[3 * i] = g.dmean[0]; out.means3D[3 * i + 1] = g.dmean[1]; out.means3D[3 * i + 2] = g.dmean[2]; }
     if (out.means2D) { out.means2D[3 * i] = g.dmean2D[0]; out.means2D[3 * i + 1] = g.dmean2D[1]; }
     if (out.opacities) out.opacities[i] = g.dopacity;
@@ -223,9 +277,17 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
 #pragma unroll
         for (int k = 0; k < 6; ++k) out.cov3D_precomp[6 * (size_t)i + k] = g.dcov[k];
     }
-    if (out.shs && shs) {
+    constexpr int K3 = 3 * (DEG + 1) * (DEG + 1);
+    if constexpr (RAW) {
+        if (out.shs) { out.shs[3 * (size_t)i] = dsh[0]; out.shs[3 * (size_t)i + 1] = dsh[1]; out.shs[3 * (size_t)i + 2] = dsh[2]; }
+        if (out.shs_rest) {
+            float *dst = out.shs_rest + (size_t)i * (M - 1) * 3;
+#pragma unroll
+            for (int k = 3; k < 48; ++k)
+                if (k < K3) dst[k - 3] = dsh[k];
+        }
+    } else if (out.shs && shs) {
         float *dst = out.shs + (size_t)i * M * 3;
-        constexpr int K3 = 3 * (DEG + 1) * (DEG + 1);
 #pragma unroll
         for (int k = 0; k < 48; ++k)
             if (k < K3 && k < 3 * M) dst[k] = dsh[k];
@@ -247,18 +309,29 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
         if (out.scales && !g.cov3D_precomp) GSR_HIP_CHECK(hipMemsetAsync(out.scales, 0, P * 12, s));
         if (out.rotations && !g.cov3D_precomp) GSR_HIP_CHECK(hipMemsetAsync(out.rotations, 0, P * 16, s));
         if (out.cov3D_precomp && g.cov3D_precomp) GSR_HIP_CHECK(hipMemsetAsync(out.cov3D_precomp, 0, P * 24, s));
-        if (out.shs && g.shs) GSR_HIP_CHECK(hipMemsetAsync(out.shs, 0, P * 12 * (size_t)f.M, s));
+        if (out.shs && g.shs) GSR_HIP_CHECK(hipMemsetAsync(out.shs, 0, P * 12 * (size_t)(g.raw ? 1 : f.M), s));
+        if (g.raw && out.shs_rest && f.M > 1) GSR_HIP_CHECK(hipMemsetAsync(out.shs_rest, 0, P * 12 * (size_t)(f.M - 1), s));
         if (n_ranks > 0) {
             const int sgrid = (n_ranks + kGeomBlock - 1) / kGeomBlock;
-#define GSR_GS(DEG)                                                                                                  \
-    hipLaunchKernelGGL(k_geom_bwd_sparse<DEG>, dim3(sgrid), dim3(kGeomBlock), 0, s, f, n_ranks, gw.order, cam.viewmatrix, \
-                       cam.projmatrix, cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.shs,         \
-                       g.colors_precomp ? 1 : 0, radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads), out)
-            switch (g.shs ? f.D : 0) {
-                case 0: GSR_GS(0); break;
-                case 1: GSR_GS(1); break;
-                case 2: GSR_GS(2); break;
-                default: GSR_GS(3); break;
+#define GSR_GS(DEG, RAW)                                                                                                     \
+    hipLaunchKernelGGL((k_geom_bwd_sparse<DEG, RAW>), dim3(sgrid), dim3(kGeomBlock), 0, s, f, n_ranks, gw.order, cam.viewmatrix, \
+                       cam.projmatrix, cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs,      \
+                       g.shs_rest, g.colors_precomp ? 1 : 0, radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads),   \
+                       out)
+            if (g.raw) {
+                switch (f.D) {
+                    case 0: GSR_GS(0, true); break;
+                    case 1: GSR_GS(1, true); break;
+                    case 2: GSR_GS(2, true); break;
+                    default: GSR_GS(3, true); break;
+                }
+            } else {
+                switch (g.shs ? f.D : 0) {
+                    case 0: GSR_GS(0, false); break;
+                    case 1: GSR_GS(1, false); break;
+                    case 2: GSR_GS(2, false); break;
+                    default: GSR_GS(3, false); break;
+                }
             }
 #undef GSR_GS
         }
@@ -267,15 +340,24 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
     }
     const int grid = (g1 - g0 + kGeomBlock - 1) / kGeomBlock;
     ProfileScope prof("geom_bwd", s);
-#define GSR_GB(DEG)                                                                                               \
-    hipLaunchKernelGGL(k_geom_bwd<DEG>, dim3(grid), dim3(kGeomBlock), 0, s, f, g0, g1, cam.viewmatrix, cam.projmatrix, \
-                       cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.shs, g.colors_precomp ? 1 : 0, \
-                       radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads), out)
-    switch (g.shs ? f.D : 0) {
-        case 0: GSR_GB(0); break;
-        case 1: GSR_GB(1); break;
-        case 2: GSR_GB(2); break;
-        default: GSR_GB(3); break;
+#define GSR_GB(DEG, RAW)                                                                                                  \
+    hipLaunchKernelGGL((k_geom_bwd<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, g0, g1, cam.viewmatrix, cam.projmatrix, \
+                       cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs, g.shs_rest,         \
+                       g.colors_precomp ? 1 : 0, radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads), out)
+    if (g.raw) {
+        switch (f.D) {
+            case 0: GSR_GB(0, true); break;
+            case 1: GSR_GB(1, true); break;
+            case 2: GSR_GB(2, true); break;
+            default: GSR_GB(3, true); break;
+        }
+    } else {
+        switch (g.shs ? f.D : 0) {
+            case 0: GSR_GB(0, false); break;
+            case 1: GSR_GB(1, false); break;
+            case 2: GSR_GB(2, false); break;
+            default: GSR_GB(3, false); break;
+        }
     }
 #undef GSR_GB
     GSR_LAUNCH_CHECK("geom_bwd", debug, s);

@@ -462,6 +462,33 @@ GSR_HD void geom_backward_one(const FrameK &f, const float *V, const float *PV, 
     }
 }
 
+// ---- the activations of the reference's parameter store, for the raw-parameter mode
+// (scene/gaussian_model.py:47-60: scaling exp, opacity sigmoid, rotation torch.nn.functional.normalize with
+// eps 1e-12; :108-127 getters).  activate_raw_backward turns the gradients w.r.t. the activated values into
+// gradients w.r.t. the raw parameters, in place.
+struct RawAct {
+    float scale[3], q[4], opacity, inv_norm;
+    bool clamped_norm;     // |raw quaternion| < eps: normalize() divided by eps, not by the norm
+};
+
+GSR_HD void activate_raw(const float log_scale[3], const float raw_q[4], float logit, RawAct &a)
+{
+    for (int k = 0; k < 3; ++k) a.scale[k] = expf(log_scale[k]);
+    const float n = sqrtf(raw_q[0] * raw_q[0] + raw_q[1] * raw_q[1] + raw_q[2] * raw_q[2] + raw_q[3] * raw_q[3]);
+    a.clamped_norm = n < 1e-12f;
+    a.inv_norm = 1.f / fmaxf(n, 1e-12f);
+    for (int k = 0; k < 4; ++k) a.q[k] = raw_q[k] * a.inv_norm;
+    a.opacity = 1.f / (1.f + expf(-logit));
+}
+
+GSR_HD void activate_raw_backward(const RawAct &a, GeomGrad &g)
+{
+    for (int k = 0; k < 3; ++k) g.dscale[k] *= a.scale[k];
+    const float dot = a.clamped_norm ? 0.f : a.q[0] * g.drot[0] + a.q[1] * g.drot[1] + a.q[2] * g.drot[2] + a.q[3] * g.drot[3];
+    for (int k = 0; k < 4; ++k) g.drot[k] = (g.drot[k] - a.q[k] * dot) * a.inv_norm;
+    g.dopacity *= a.opacity * (1.f - a.opacity);
+}
+
 // ---- A.1 alone (markVisible).
 GSR_HD bool in_frustum(const float p[3], const float *V)
 {

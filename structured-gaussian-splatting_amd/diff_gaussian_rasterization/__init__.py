@@ -56,7 +56,7 @@ def _f32c(t: Optional[torch.Tensor], device=None) -> Optional[torch.Tensor]:
 
 class _Frame:
     """Native handles of one forward pass, kept alive by autograd's ctx for the backward."""
-    __slots__ = ("desc", "cam", "keep", "plan", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device")
+    __slots__ = ("desc", "cam", "keep", "plan", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device", "raw")
 
     @property
     def R(self):
@@ -73,8 +73,10 @@ def _camera(rs: GaussianRasterizationSettings, device):
 
 
 def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                      rs: GaussianRasterizationSettings, tile_rows=None, out_color=None):
-    """Stage 1 + stage 2 of the native forward.  Returns (color, radii, frame)."""
+                      rs: GaussianRasterizationSettings, tile_rows=None, out_color=None, sh_rest=None, raw=False):
+    """Stage 1 + stage 2 of the native forward.  Returns (color, radii, frame).
+    raw=True: the tensors are the parameter store's RAW values (sh = _features_dc, sh_rest = _features_rest,
+    opacities = logits, scales = log-scales, rotations = unnormalised) and the activations run in the kernels."""
     device = means3D.device
     if device.type != "cuda":
         raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a HIP device; "
@@ -85,15 +87,21 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
     sh, colors_precomp = _f32c(sh, device), _f32c(colors_precomp, device)
     opacities = _f32c(opacities, device)
     scales, rotations, cov3D_precomp = _f32c(scales, device), _f32c(rotations, device), _f32c(cov3D_precomp, device)
+    sh_rest = _f32c(sh_rest, device)
     M = int(sh.shape[1]) if sh is not None else 0
+    if raw:
+        if sh is None or M != 1 or scales is None or rotations is None or colors_precomp is not None or cov3D_precomp is not None:
+            raise ValueError("raw mode takes features_dc [P,1,3], features_rest [P,M-1,3], log-scales and raw rotations")
+        M = 1 + (int(sh_rest.shape[1]) if sh_rest is not None else 0)
     fr = _Frame()
     fr.device, fr.M = device, M
     fr.desc = N.make_desc(P, int(rs.sh_degree), M, W, H, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.prefiltered,
                           rs.debug, tile_rows)
     fr.cam, cam_keep = _camera(rs, device)
     fr.gauss = N.Gaussians(N._ptr(means3D), N._ptr(sh), N._ptr(colors_precomp), N._ptr(opacities), N._ptr(scales),
-                           N._ptr(rotations), N._ptr(cov3D_precomp))
-    fr.keep = (cam_keep, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp)
+                           N._ptr(rotations), N._ptr(cov3D_precomp), N._ptr(sh_rest), 1 if raw else 0)
+    fr.keep = (cam_keep, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest)
+    fr.raw = bool(raw)
     geom_bytes, image_bytes = N.workspace_sizes(fr.desc)
     fr.geom_ws = torch.empty(geom_bytes, dtype=torch.uint8, device=device)
     fr.image_ws = torch.empty(image_bytes, dtype=torch.uint8, device=device)
@@ -124,10 +132,11 @@ def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.T
 def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int = 0, g1: Optional[int] = None,
                             binned_ranks: Optional[int] = None):
     """K8 + K9 on Gaussians [g0, g1).  `needs` = (means3D, means2D, sh, colors, opacities, scales, rotations,
-    cov3D) booleans.  Returns the 8 gradient tensors (None where not needed / not applicable)."""
+    cov3D[, sh_rest]) booleans.  Returns the 8 gradient tensors (None where not needed / not applicable); for a
+    raw-mode frame 9: sh is then d/d_features_dc [P,1,3] and the ninth d/d_features_rest [P,M-1,3]."""
     P, M, dev = fr.desc.P, fr.M, fr.device
     g1 = P if g1 is None else g1
-    (_, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp) = fr.keep
+    (_, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest) = fr.keep
     partial = (g0, g1) != (0, P)
     alloc = torch.zeros if partial else torch.empty
 
@@ -135,20 +144,23 @@ def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int =
         return alloc(*shape, dtype=torch.float32, device=dev) if (flag and present) else None
     g_means3D = mk(needs[0], True, P, 3)
     g_means2D = mk(needs[1], True, P, 3)
-    g_sh = mk(needs[2], sh is not None, P, M, 3)
+    g_sh = mk(needs[2], sh is not None, P, 1 if fr.raw else M, 3)
+    g_rest = mk(fr.raw and len(needs) > 8 and needs[8], sh_rest is not None, P, M - 1, 3)
     g_col = mk(needs[3], colors_precomp is not None, P, 3)
     g_op = mk(needs[4], True, P, 1)
     g_sc = mk(needs[5], scales is not None, P, 3)
     g_rot = mk(needs[6], rotations is not None, P, 4)
     g_cov = mk(needs[7], cov3D_precomp is not None, P, 6)
     grads = N.Grads(N._ptr(g_means3D), N._ptr(g_means2D), N._ptr(g_sh), N._ptr(g_col), N._ptr(g_op), N._ptr(g_sc),
-                    N._ptr(g_rot), N._ptr(g_cov))
+                    N._ptr(g_rot), N._ptr(g_cov), N._ptr(g_rest))
     if P > 0 and g1 > g0:
         with torch.cuda.device(dev):
             if binned_ranks is None:        # gradients of this very frame: its own binned depth prefix
                 plan = fr.plan
                 binned_ranks = int(plan.chunk_rank_begin[plan.chunks_run]) if plan.num_rendered > 0 and plan.chunks_run > 0 else 0
             N.backward_geom(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, g0, g1, grads, dev, binned_ranks)
+    if fr.raw:
+        return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, g_rest
     return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov
 
 
@@ -212,6 +224,38 @@ class _RasterizeGaussians(torch.autograd.Function):
         return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None
 
 
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """SURVEY 8a row a14 fused: same rasterizer, fed with the parameter store's RAW tensors.  The activations of
+    scene/gaussian_model.py:47-60 (exp, sigmoid, normalize) and the torch.cat of get_features (:120-123) run inside
+    the preprocess kernel, their chain rule inside the geometry backward: gradients arrive on the raw parameters."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_logits, log_scales, raw_rotations, raster_settings):
+        rs = raster_settings
+        color, radii, frame = rasterize_forward(xyz, features_dc, None, opacity_logits, log_scales, raw_rotations, None, rs,
+                                                sh_rest=features_rest, raw=True)
+        if rs.debug:
+            torch.cuda.synchronize(xyz.device)
+        ctx.frame = frame
+        ctx.shapes = (means2D.shape, opacity_logits.shape)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _grad_radii):
+        fr = ctx.frame
+        n = ctx.needs_input_grad       # xyz, means2D, f_dc, f_rest, opacity, scales, rotations
+        needs = (n[0], n[1], n[2], False, n[4], n[5], n[6], False, n[3])
+        screen = rasterize_backward_screen(fr, grad_out_color)
+        g_xyz, g_means2D, g_dc, _, g_op, g_sc, g_rot, _, g_rest = rasterize_backward_geom(fr, screen, needs)
+        if g_op is not None:
+            g_op = g_op.view(ctx.shapes[1])
+        if g_means2D is not None:
+            g_means2D = g_means2D.view(ctx.shapes[0])
+        ctx.frame = None
+        return g_xyz, g_means2D, g_dc, g_rest, g_op, g_sc, g_rot, None
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
@@ -253,3 +297,15 @@ class GaussianRasterizer(nn.Module):
                          image_width=int(rs.image_width))
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, rs)
+
+    def forward_raw(self, xyz, means2D, features_dc, features_rest, opacity_logits, log_scales, raw_rotations):
+        """Extension (not in the reference API): render straight from the reference GaussianModel's raw parameters
+        (`_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation`), activations fused into the kernels.
+        Same pixels and radii as forward(get_xyz, ..., get_opacity, get_features, get_scaling, get_rotation) and the
+        same gradients on the raw parameters as autograd through those getters, to fp32 rounding."""
+        rs = self.raster_settings
+        rs = rs._replace(sh_degree=int(rs.sh_degree), image_height=int(rs.image_height), image_width=int(rs.image_width))
+        if features_rest is None or features_rest.numel() == 0:
+            features_rest = torch.empty(0, dtype=torch.float32, device=xyz.device)
+        return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_logits, log_scales,
+                                            raw_rotations, rs)

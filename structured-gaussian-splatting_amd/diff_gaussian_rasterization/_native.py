@@ -33,12 +33,14 @@ class Camera(C.Structure):
 
 class Gaussians(C.Structure):
     _fields_ = [("means3D", _f32p), ("shs", _f32p), ("colors_precomp", _f32p), ("opacities", _f32p),
-                ("scales", _f32p), ("rotations", _f32p), ("cov3D_precomp", _f32p)]
+                ("scales", _f32p), ("rotations", _f32p), ("cov3D_precomp", _f32p),
+                ("shs_rest", _f32p), ("raw", C.c_int32)]      # raw-parameter mode (a14): see include/gsrast.h
 
 
 class Grads(C.Structure):
     _fields_ = [("means3D", _f32p), ("means2D", _f32p), ("shs", _f32p), ("colors_precomp", _f32p),
-                ("opacities", _f32p), ("scales", _f32p), ("rotations", _f32p), ("cov3D_precomp", _f32p)]
+                ("opacities", _f32p), ("scales", _f32p), ("rotations", _f32p), ("cov3D_precomp", _f32p),
+                ("shs_rest", _f32p)]
 
 
 MAX_CHUNKS = 8

@@ -54,3 +54,4 @@ class Pipe:
     convert_SHs_python = False
     compute_cov3D_python = False
     debug = False
+    fused_activations = False      # extension: see gaussian_renderer.render

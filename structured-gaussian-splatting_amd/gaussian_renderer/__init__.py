@@ -3,6 +3,11 @@
 selection (`pipe.compute_cov3D_python`, `pipe.convert_SHs_python`, `override_color`); `pc` is anything
 with the reference GaussianModel's getters (get_xyz, get_opacity, get_scaling, get_rotation,
 get_features, get_covariance, active_sh_degree, max_sh_degree).
+
+Extension: `pipe.fused_activations = True` (not a reference flag; default off) renders from
+the model's raw parameters `_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation` with the
+activations fused into the HIP kernels (GaussianRasterizer.forward_raw) — same image, same gradients on the
+parameters, without the ~30 torch kernels of the getters and their backward.
 """
 import math
 
@@ -53,6 +58,13 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.compute_cov3D_python
+            and not pipe.convert_SHs_python and hasattr(pc, "_features_rest")):
+        rendered_image, radii = rasterizer.forward_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest,
+                                                       pc._opacity, pc._scaling, pc._rotation)
+        return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+                "radii": radii}
 
     scales = rotations = cov3D_precomp = None
     if pipe.compute_cov3D_python:

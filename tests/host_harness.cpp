@@ -65,3 +65,27 @@ extern "C" void hh_tile_may_contribute(int n, const float *sx, const float *sy, 
 {
     for (int i = 0; i < n; ++i) out[i] = tile_may_contribute(sx[i], sy[i], A[i], B[i], C[i], op[i], tx[i], ty[i]) ? 1 : 0;
 }
+
+// a14: activations of the raw parameters and their chain rule (gsr_math.h activate_raw / activate_raw_backward).
+// in: log_scales[n,3], raw_q[n,4], logits[n]; upstream d_scale[n,3], d_q[n,4], d_op[n]
+// out: scale[n,3], q[n,4], op[n] and the gradients w.r.t. the raw values in g_ls[n,3], g_rq[n,4], g_logit[n]
+extern "C" void hh_activate_raw(int n, const float *log_scales, const float *raw_q, const float *logits, const float *d_scale,
+                                const float *d_q, const float *d_op, float *scale, float *q, float *op, float *g_ls,
+                                float *g_rq, float *g_logit)
+{
+    for (int i = 0; i < n; ++i) {
+        RawAct a;
+        activate_raw(log_scales + 3 * i, raw_q + 4 * i, logits[i], a);
+        for (int k = 0; k < 3; ++k) scale[3 * i + k] = a.scale[k];
+        for (int k = 0; k < 4; ++k) q[4 * i + k] = a.q[k];
+        op[i] = a.opacity;
+        GeomGrad g;
+        for (int k = 0; k < 3; ++k) g.dscale[k] = d_scale[3 * i + k];
+        for (int k = 0; k < 4; ++k) g.drot[k] = d_q[4 * i + k];
+        g.dopacity = d_op[i];
+        activate_raw_backward(a, g);
+        for (int k = 0; k < 3; ++k) g_ls[3 * i + k] = g.dscale[k];
+        for (int k = 0; k < 4; ++k) g_rq[4 * i + k] = g.drot[k];
+        g_logit[i] = g.dopacity;
+    }
+}

@@ -678,3 +678,49 @@ def test_more_than_2_pow_32_tile_instances_is_an_error_not_a_wrap():
     assert fr.R == P * 16 * 256 and int((radii > 0).sum()) == P
     assert fr.plan.chunks_run == 1 and 0 <= fr.plan.instances_emitted < fr.R // 100
     assert torch.isfinite(color).all() and float(color[:, :256].abs().sum()) > 0 and float(color[:, 256:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("D,max_D", [(3, 3), (1, 3), (0, 0)])
+def test_raw_parameter_mode_equals_getters_plus_standard_api(D, max_D):
+    """SURVEY 8a row a14 fused (`pipe.fused_activations`, GaussianRasterizer.forward_raw): rendering from the raw
+    parameters with the activations inside the kernels gives the image of render() through the getters and the
+    same gradients on the raw parameters as torch autograd through exp / sigmoid / normalize / cat."""
+    from gaussian_params import GaussianParams, Pipe
+    from gaussian_renderer import render
+    W, H = 320, 208
+    scene = S.make_scene(20_000, W, H, max_D, 17 + D, scale_lo=0.005, scale_hi=0.06).to(DEV)
+    cam = S.make_camera(W, H).to(DEV)
+    bg = torch.tensor([0.1, 0.0, 0.2], device=DEV)
+    gimg = S.make_grad_image(W, H, 6).to(DEV)
+    results = []
+    for fused in (False, True):
+        model = GaussianParams(scene, max_sh_degree=max_D).to(DEV)
+        model.active_sh_degree = D
+        pipe = Pipe()
+        pipe.fused_activations = fused
+        out = render(cam, model, pipe, bg)
+        out["render"].backward(gimg)
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        results.append((out["render"].detach(), out["radii"], out["viewspace_points"].grad.detach().clone(), grads))
+    (img_a, rad_a, vp_a, g_a), (img_b, rad_b, vp_b, g_b) = results
+    assert int((rad_a != rad_b).sum()) <= 2                     # exp() may differ in the last bit: ceil() boundary
+    # exp / sigmoid evaluated in the kernel may differ from torch's in the last bit, which can flip a discrete blend
+    # decision (alpha < 1/255, T < 1e-4) on a pixel: all but a handful of pixels agree to 2e-5, those to one splat
+    derr = (img_a - img_b).abs().amax(0)
+    assert float((derr > 2e-5).float().mean()) <= 1e-4 and float(derr.max()) <= 8e-3
+    names = ["_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"] + (["_features_rest"] if max_D > 0 else [])
+    assert set(names) <= set(g_a) and set(names) <= set(g_b)
+    for n in names:
+        a, b = g_a[n].reshape(g_a[n].shape[0], -1), g_b[n].reshape(g_b[n].shape[0], -1)
+        assert a.shape == b.shape, n
+        scale = float(a.abs().max())
+        assert scale > 0, n
+        err = (a - b).abs()
+        bad_rows = (err > 2e-5 * scale + 2e-3 * a.abs()).any(1)
+        assert float(bad_rows.float().mean()) <= 2e-4, f"{n}: {int(bad_rows.sum())} rows differ"
+        assert float((a - b).norm() / a.norm()) <= 1e-4, n
+    assert float((vp_a - vp_b).norm() / vp_a.norm()) <= 1e-4
+    if D < max_D:                                               # coefficients above the active degree get exact zeros
+        K = (D + 1) ** 2
+        assert float(g_b["_features_rest"][:, K - 1:].abs().max()) == 0.0

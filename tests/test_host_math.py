@@ -160,3 +160,32 @@ def test_tile_culling_is_conservative(hh):
         alpha = np.minimum(0.99, co_[:, 3, None, None] * np.exp(np.minimum(power, 0)))
         accept = (power <= 0) & (alpha >= (1 / 255) * (1 - 1e-3))
         assert not accept.any(), f"{accept.any((1, 2)).sum()} culled instances have an accepting pixel"
+
+
+def test_raw_activations_match_torch_autograd(hh):
+    """csrc/gsr_math.h activate_raw / activate_raw_backward (raw-parameter mode) against torch
+    autograd through the reference's activations (scene/gaussian_model.py:47-60: exp, sigmoid,
+    torch.nn.functional.normalize), including a zero quaternion (normalize's eps branch)."""
+    n = 500
+    g = torch.Generator().manual_seed(3)
+    ls = (torch.rand(n, 3, generator=g) * 8 - 7).requires_grad_(True)
+    rq = torch.randn(n, 4, generator=g)
+    rq[0] = 0.0
+    rq[1] *= 1e-3
+    rq.requires_grad_(True)
+    lo = (torch.randn(n, generator=g) * 3).requires_grad_(True)
+    d_s, d_q, d_o = torch.randn(n, 3, generator=g), torch.randn(n, 4, generator=g), torch.randn(n, generator=g)
+    s, q, o = torch.exp(ls), torch.nn.functional.normalize(rq), torch.sigmoid(lo)
+    ((s * d_s).sum() + (q * d_q).sum() + (o * d_o).sum()).backward()
+    f = lambda t: np.ascontiguousarray(t.detach().numpy(), np.float32)
+    out = {k: np.zeros(shape, np.float32) for k, shape in dict(s=(n, 3), q=(n, 4), o=(n,), gls=(n, 3), grq=(n, 4), glo=(n,)).items()}
+    hh.hh_activate_raw(n, _p(f(ls)), _p(f(rq)), _p(f(lo)), _p(f(d_s)), _p(f(d_q)), _p(f(d_o)), _p(out["s"]), _p(out["q"]),
+                       _p(out["o"]), _p(out["gls"]), _p(out["grq"]), _p(out["glo"]))
+    np.testing.assert_allclose(out["s"], f(s), rtol=2e-6)
+    np.testing.assert_allclose(out["q"], f(q), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(out["o"], f(o), rtol=2e-6, atol=1e-8)
+    np.testing.assert_allclose(out["gls"], f(ls.grad), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out["glo"], f(lo.grad), rtol=1e-5, atol=1e-7)
+    # row 0 (zero quaternion) divides by eps = 1e-12 on both sides; compare relative to the row's scale
+    err = np.abs(out["grq"] - f(rq.grad))
+    assert (err <= 1e-5 * np.abs(f(rq.grad)).max(axis=1, keepdims=True) + 1e-6).all()
