@@ -194,6 +194,13 @@ int gsr_dist2_knn3(int32_t P, const float *xyz, float *mean_dist2, void *workspa
 int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, int64_t step, void *stream);
 
+/* ---- the densification bookkeeping of one training iteration (train.py:127-130,
+ * scene/gaussian_model.py:415-417) in one pass without a host synchronisation: for every Gaussian with
+ * radii[i] > 0:  max_radii2D[i] = max(max_radii2D[i], radii[i]);  xyz_gradient_accum[i] += |viewspace_grad[i, :2]|;
+ * denom[i] += 1.  viewspace_grad is [P,3] (the means2D gradient of the rasterizer). */
+int gsr_densify_stats(int32_t P, const int32_t *radii, const float *viewspace_grad, float *max_radii2D,
+                      float *xyz_gradient_accum, float *denom, void *stream);
+
 /* Test hook for the hand-written radix sort (csrc/gsr_sort.hip): stable sort of n (key, value) u32 pairs on
  * key bits [0, end_bit).  keys0/vals0 hold the input; *result_buffer says which pair of buffers holds the
  * output.  count_on_device != 0 reads n from a device word (as the progressive binning does). */

@@ -36,9 +36,43 @@ __global__ __launch_bounds__(kAdamBlock) void k_adam(size_t n, float *__restrict
 #undef GSR_ADAM1
 }
 
+// ---- densification bookkeeping of one training iteration (train.py:127-130 + scene/gaussian_model.py:415-417):
+//   max_radii2D[vis] = max(max_radii2D[vis], radii[vis]);  xyz_gradient_accum[vis] += |viewspace grad.xy|;  denom[vis] += 1
+// with vis = radii > 0.  One pass and no host synchronisation, where boolean-mask indexing costs four nonzero()
+// compactions (each a device->host size readback) and ~20 kernels.
+__global__ __launch_bounds__(256) void k_densify_stats(int P, const int32_t *__restrict__ radii, const float *__restrict__ vs_grad,
+                                                       float *__restrict__ max_radii2D, float *__restrict__ grad_accum,
+                                                       float *__restrict__ denom)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    const float gx = vs_grad[3 * (size_t)i], gy = vs_grad[3 * (size_t)i + 1];
+    grad_accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.f;
+}
+
 }  // namespace gsr
 
 using namespace gsr;
+
+extern "C" int gsr_densify_stats(int32_t P, const int32_t *radii, const float *viewspace_grad, float *max_radii2D,
+                                 float *xyz_gradient_accum, float *denom, void *stream)
+{
+    if (P < 0 || (P > 0 && (!radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom))) {
+        set_error("gsr_densify_stats: bad argument");
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0) return GSR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfileScope prof("densify_stats", s);
+    hipLaunchKernelGGL(k_densify_stats, dim3((P + 255) / 256), dim3(256), 0, s, P, radii, viewspace_grad, max_radii2D,
+                       xyz_gradient_accum, denom);
+    GSR_LAUNCH_CHECK("densify_stats", false, s);
+    return GSR_OK;
+}
 
 extern "C" int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
                              float beta2, float eps, int64_t step, void *stream)

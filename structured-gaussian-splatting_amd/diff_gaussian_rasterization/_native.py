@@ -62,7 +62,7 @@ class DebugViews(C.Structure):
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
            "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward",
-           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step")
+           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_densify_stats")
 
 _lib = None
 
@@ -266,3 +266,8 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     _check(load().gsr_adam_step(C.c_int64(param.numel()), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), C.c_float(lr),
                                 C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_int64(int(step)),
                                 _stream(param.device)), "gsr_adam_step")
+
+
+def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom):
+    _check(load().gsr_densify_stats(C.c_int32(radii.shape[0]), _ptr(radii), _ptr(viewspace_grad), _ptr(max_radii2D),
+                                    _ptr(xyz_gradient_accum), _ptr(denom), _stream(radii.device)), "gsr_densify_stats")

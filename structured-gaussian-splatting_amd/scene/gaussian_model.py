@@ -233,6 +233,19 @@ class GaussianModel:
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
         self.denom[update_filter] += 1
 
+    def update_densification_stats(self, viewspace_point_tensor, radii):
+        """train.py:127-130 in one native pass (gsr_densify_stats): max_radii2D and add_densification_stats for the
+        visible set `radii > 0`, without the four boolean-mask compactions (each a host synchronisation)."""
+        grad = viewspace_point_tensor.grad
+        if grad is None or not self.max_radii2D.is_cuda:
+            vis = radii > 0
+            self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis])
+            self.add_densification_stats(viewspace_point_tensor, vis)
+            return
+        from diff_gaussian_rasterization import _native
+        with torch.cuda.device(radii.device):
+            _native.densify_stats(radii.contiguous(), grad.contiguous(), self.max_radii2D, self.xyz_gradient_accum, self.denom)
+
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0

@@ -27,8 +27,7 @@ def train(gaussians, cameras, targets, opt, pipe, background, iterations, first_
         loss.backward()
         with torch.no_grad():
             if it < opt.densify_until_iter:
-                gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis])
-                gaussians.add_densification_stats(vsp, vis)
+                gaussians.update_densification_stats(vsp, radii)       # train.py:127-130, one native pass
                 if it > opt.densify_from_iter and it % opt.densification_interval == 0:
                     size_threshold = 20 if it > opt.opacity_reset_interval else None
                     gaussians.densify_and_prune(opt.densify_grad_threshold, 0.005, scene_extent, size_threshold)

@@ -724,3 +724,27 @@ def test_raw_parameter_mode_equals_getters_plus_standard_api(D, max_D):
     if D < max_D:                                               # coefficients above the active degree get exact zeros
         K = (D + 1) ** 2
         assert float(g_b["_features_rest"][:, K - 1:].abs().max()) == 0.0
+
+
+def test_native_densification_stats_equal_masked_torch_ops():
+    """GaussianModel.update_densification_stats (gsr_densify_stats) against the reference's masked updates
+    (train.py:127-130, scene/gaussian_model.py:415-417) applied twice with different visible sets."""
+    from scene import GaussianModel
+    P = 50_000
+    gm = GaussianModel(0)
+    gm.adopt_scene(S.make_scene(P, 64, 64, 0, 3), device=DEV)
+    gm.training_setup(__import__("scene").OptimizationDefaults())
+    ref = dict(mr=torch.zeros(P, device=DEV), acc=torch.zeros(P, 1, device=DEV), den=torch.zeros(P, 1, device=DEV))
+    g = torch.Generator().manual_seed(1)
+    for _ in range(2):
+        radii = (torch.randint(-3, 40, (P,), generator=g).clamp_min(0)).to(torch.int32).to(DEV)
+        vsp = torch.zeros(P, 3, device=DEV, requires_grad=True)
+        vsp.grad = torch.randn(P, 3, generator=g).to(DEV)
+        gm.update_densification_stats(vsp, radii)
+        vis = radii > 0
+        ref["mr"][vis] = torch.max(ref["mr"][vis], radii[vis])
+        ref["acc"][vis] += torch.norm(vsp.grad[vis, :2], dim=-1, keepdim=True)
+        ref["den"][vis] += 1
+    torch.cuda.synchronize()
+    assert torch.equal(gm.max_radii2D, ref["mr"]) and torch.equal(gm.denom, ref["den"])
+    assert torch.allclose(gm.xyz_gradient_accum, ref["acc"], rtol=1e-6, atol=1e-7)
