@@ -219,13 +219,16 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *
     BinningWS bw = carve_binning(binning_ws, plan->num_rendered);
     if ((rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
     int sort_result = 0;
+    uint64_t cand_before = 0;                       // upper bound of the instances earlier chunks can have emitted
     // Early stop: one control-block readback per chunk (~10 us of stream idle, measured); the chunk plan keeps
     // the number of chunks at three or fewer.
     for (int c = 0; c < plan->num_chunks; ++c) {
         const bool last = c == plan->num_chunks - 1;
         const int r0 = plan->chunk_rank_begin[c], r1 = plan->chunk_rank_begin[c + 1];
-        if ((rc = launch_chunk_binning(f, c, r0, r1, (uint64_t)plan->chunk_instances_max[c], gw, bw, iw, &sort_result, dbg, s)))
+        if ((rc = launch_chunk_binning(f, c, r0, r1, (uint64_t)plan->chunk_instances_max[c], cand_before, gw, bw, iw, &sort_result,
+                                       dbg, s)))
             return rc;
+        cand_before += (uint64_t)plan->chunk_instances_max[c];
         if ((rc = launch_render_fwd(f, *cam, c, last, gw, bw, iw, out_color, dbg, s))) return rc;
         plan->chunks_run = c + 1;
         plan->instances_emitted = -1;                 // the last chunk's count stays on the device

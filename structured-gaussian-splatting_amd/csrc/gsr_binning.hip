@@ -66,6 +66,7 @@ ImageWS carve_image(void *base, const FrameK &f)
     w.last_enc = (int32_t *)(b + o); o += align_up((N ? N : 1) * 4);
     w.ranges = (uint2 *)(b + o); o += align_up((Tn ? Tn : 1) * 8 * GSR_MAX_CHUNKS);
     w.open = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
+    w.open_bits = (unsigned long long *)(b + o); o += align_up((size_t)(f.Gy > 0 ? f.Gy : 1) * (size_t)((f.Gx + 63) / 64 + 1) * 8);
     w.ctrl_scratch = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
     w.total = o;
     return w;
@@ -194,23 +195,29 @@ int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
     return GSR_OK;
 }
 
-// ---- open flags: (re)initialise for the slab, count the tiles that are still open (one block).
-__global__ __launch_bounds__(1024) void k_open_count(FrameK f, int init, uint32_t *__restrict__ open, Ctrl *ctrl)
+// ---- open flags: (re)initialise for the slab, count the tiles that are still open and pack the flags into one
+// bit per tile (row-major, ceil(Gx/64) words per tile row) for the count / emit kernels (one block).
+__global__ __launch_bounds__(1024) void k_open_count(FrameK f, int init, uint32_t *__restrict__ open,
+                                                     unsigned long long *__restrict__ open_bits, Ctrl *ctrl)
 {
     __shared__ uint32_t sh_count;
     if (threadIdx.x == 0) sh_count = 0;
     __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int W64 = (f.Gx + 63) >> 6;
     uint32_t mine = 0;
-    for (int t = threadIdx.x; t < f.Gx * f.Gy; t += blockDim.x) {
-        if (init) {
-            const int ty = t / f.Gx;
-            open[t] = (ty >= f.ty0 && ty < f.ty1) ? 1u : 0u;
+    for (int j = wave; j < f.Gy * W64; j += n_waves) {        // one wave per (tile row, 64-tile word)
+        const int ty = j / W64, tx = (j - ty * W64) * 64 + lane;
+        uint32_t o = 0;
+        if (tx < f.Gx) {
+            const int t = ty * f.Gx + tx;
+            if (init) { o = (ty >= f.ty0 && ty < f.ty1) ? 1u : 0u; open[t] = o; }
+            else o = open[t];
         }
-        mine += open[t];
+        const unsigned long long m = __ballot(o != 0u);
+        if (lane == 0) { open_bits[j] = m; mine += (uint32_t)__popcll(m); }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&sh_count, mine);
+    if (lane == 0 && mine) atomicAdd(&sh_count, mine);
     __syncthreads();
     if (threadIdx.x == 0) ctrl->open_count = sh_count;
 }
@@ -220,7 +227,7 @@ int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hi
     const size_t Tn = (size_t)f.Gx * f.Gy;
     GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, Tn * sizeof(uint2) * GSR_MAX_CHUNKS, s));
     ProfileScope prof("open_count", s);
-    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 1, iw.open, gw.ctrl);
+    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 1, iw.open, iw.open_bits, gw.ctrl);
     GSR_LAUNCH_CHECK("open_count(init)", debug, s);
     return GSR_OK;
 }
@@ -228,90 +235,279 @@ int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hi
 int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
 {
     ProfileScope prof("open_count", s);
-    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 0, iw.open, gw.ctrl);
+    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 0, iw.open, iw.open_bits, gw.ctrl);
     GSR_LAUNCH_CHECK("open_count", debug, s);
     return GSR_OK;
 }
 
-// ---- per chunk: count the instances each Gaussian will emit: tiles of its rectangle that are still open AND
-// that its alpha >= 1/255 ellipse can reach (tile_may_contribute: exact culling, no pixel changes).  One WAVE
-// per Gaussian, 64 tiles per step, so screen-filling splats do not serialise on a lane.
-__device__ __forceinline__ bool instance_wanted(const FrameK &f, const TileRect &t, int w, int i, int total,
-                                                const float4 &a, const float4 &b, const uint32_t *__restrict__ open,
-                                                uint32_t &tile)
+// ---- variant A (chunks of few, large splats — the nearest ones): a TEAM of W waves (one block) per Gaussian walks
+// its rectangle 64 tiles per wave step.  A tile takes an instance iff it is still open AND the splat's
+// alpha >= 1/255 ellipse can reach it (tile_may_contribute: exact culling, no pixel changes).  The count pass
+// keeps each step's 64-bit acceptance mask (scratch in the idle radix buffer), so the emit pass evaluates nothing:
+// it scans the masks' popcounts and expands them into (tile, slot, Gaussian) triples in rectangle order.
+__device__ __forceinline__ uint32_t mask_base(const uint32_t *__restrict__ offs_full, int r0, int r, uint32_t total)
 {
-    if (i >= total) return false;
-    const int tx = t.x0 + i % w, ty = t.y0 + i / w;
-    tile = (uint32_t)(ty * f.Gx + tx);
-    float A, B, C, op;
-    unscale_conic(a.z, a.w, b.x, b.y, A, B, C, op);
-    return open[tile] != 0u && tile_may_contribute(a.x, a.y, A, B, C, op, tx, ty);
+    const uint32_t cb = r0 > 0 ? offs_full[r0 - 1] : 0u;
+    const uint32_t start = offs_full[r] - total - cb;          // first candidate of rank r inside the chunk
+    return (start >> 6) + (uint32_t)(r - r0);                  // disjoint ranges of ceil(total / 64) words per rank
 }
 
-__global__ __launch_bounds__(kBinBlock) void k_count_open(FrameK f, int r0, int r1, const uint32_t *__restrict__ order,
-                                                          const float4 *__restrict__ records, const uint32_t *__restrict__ open,
-                                                          const Ctrl *__restrict__ ctrl, int chunk, uint32_t *__restrict__ cnt_open)
+template <int W>
+__global__ __launch_bounds__(W *kWave) void k_count_team(FrameK f, int c, int r0, const uint32_t *__restrict__ order,
+                                                         const float4 *__restrict__ records,
+                                                         const unsigned long long *__restrict__ open_bits,
+                                                         const Ctrl *__restrict__ ctrl, const uint32_t *__restrict__ offs_full,
+                                                         unsigned long long *__restrict__ masks, uint32_t *__restrict__ cnt_open)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * kBinBlock + threadIdx.x) >> 6;
-    const int n_waves = (gridDim.x * kBinBlock) >> 6;
-    const bool nothing_open = chunk > 0 && ctrl->open_count == 0u;
-    for (int r = r0 + wave; r < r1; r += n_waves) {
-        uint32_t cnt = 0;
-        if (!nothing_open) {
-            const uint32_t g = order[r];
-            const float4 a = records[3 * (size_t)g], b = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
-            const TileRect t = unpack_rect(cc.z, cc.w);
-            const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0);
-            for (int i0 = 0; i0 < total; i0 += kWave) {
-                uint32_t tile;
-                cnt += (uint32_t)__popcll(__ballot(instance_wanted(f, t, w, i0 + lane, total, a, b, open, tile)));
-            }
-        }
-        if (lane == 0) cnt_open[r] = cnt;
-    }
-}
-
-// ---- emit (tile, slot) pairs of the chunk's Gaussians in depth order, open tiles only.  One WAVE walks one
-// Gaussian's rectangle cooperatively (ballot + popcount gives each open tile its ordinal), so a splat that
-// covers thousands of tiles does not serialise on one lane; 4 Gaussians per 256-thread block per step.
-__global__ __launch_bounds__(kBinBlock) void k_emit(FrameK f, int c, int r0, int r1, const uint32_t *__restrict__ order,
-                                                    const float4 *__restrict__ records, const uint32_t *__restrict__ open,
-                                                    const uint32_t *__restrict__ cnt_open, const uint32_t *__restrict__ offs_open,
-                                                    const Ctrl *__restrict__ ctrl, uint32_t *__restrict__ keys,
-                                                    uint32_t *__restrict__ vals, uint32_t *__restrict__ inst_gid,
-                                                    uint32_t *__restrict__ row_begin)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * kBinBlock + threadIdx.x) >> 6;
-    const int n_waves = (gridDim.x * kBinBlock) >> 6;
-    const uint32_t base = ctrl->chunk_base[c];
-    if (ctrl->chunk_R[c] == 0u) {                       // nothing to emit (e.g. a speculatively enqueued chunk)
-        for (int r = r0 + blockIdx.x * kBinBlock + threadIdx.x; r < r1; r += gridDim.x * kBinBlock) row_begin[r] = base;
+    __shared__ uint32_t sh_cnt[W];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = r0 + (int)blockIdx.x;
+    if (c > 0 && ctrl->open_count == 0u) {                     // a speculatively enqueued chunk: nothing is open
+        if (threadIdx.x == 0) cnt_open[r] = 0;
         return;
     }
-    for (int r = r0 + wave; r < r1; r += n_waves) {
-        const uint32_t cnt = cnt_open[r];
-        const uint32_t first = base + offs_open[r] - cnt;
-        if (lane == 0) row_begin[r] = first;
-        if (cnt == 0) continue;
-        const uint32_t g = order[r];
-        const float4 a = records[3 * (size_t)g], b = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
-        const TileRect t = unpack_rect(cc.z, cc.w);
-        const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0);
-        uint32_t emitted = 0;
-        for (int i0 = 0; i0 < total; i0 += kWave) {
-            uint32_t tile = 0;
-            const bool is_open = instance_wanted(f, t, w, i0 + lane, total, a, b, open, tile);
-            const unsigned long long m = __ballot(is_open);
-            if (is_open) {
-                const uint32_t slot = first + emitted + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                keys[slot] = tile;
+    const uint32_t g = order[r];
+    const float4 a = records[3 * (size_t)g], b = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
+    const TileRect t = unpack_rect(cc.z, cc.w);
+    const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0), ns = (total + kWave - 1) >> 6;
+    const uint32_t mb = mask_base(offs_full, r0, r, (uint32_t)total);
+    const int W64 = (f.Gx + 63) >> 6;
+    float A, B, C, op;
+    unscale_conic(a.z, a.w, b.x, b.y, A, B, C, op);
+    uint32_t local = 0;
+    for (int s = wv; s < ns; s += W) {
+        const int i = s * kWave + lane;
+        bool want = false;
+        if (i < total) {
+            const int tx = t.x0 + i % w, ty = t.y0 + i / w;
+            want = ((open_bits[ty * W64 + (tx >> 6)] >> (tx & 63)) & 1ull) && tile_may_contribute(a.x, a.y, A, B, C, op, tx, ty);
+        }
+        const unsigned long long m = __ballot(want);
+        if (lane == 0) masks[mb + (uint32_t)s] = m;
+        local += (uint32_t)__popcll(m);
+    }
+    if (W == 1) {
+        if (lane == 0) cnt_open[r] = local;
+        return;
+    }
+    if (lane == 0) sh_cnt[wv] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) sum += sh_cnt[i];
+        cnt_open[r] = sum;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(W *kWave) void k_emit_team(FrameK f, int c, int r0, const uint32_t *__restrict__ order,
+                                                        const float4 *__restrict__ records, const Ctrl *__restrict__ ctrl,
+                                                        const uint32_t *__restrict__ offs_full,
+                                                        const unsigned long long *__restrict__ masks,
+                                                        const uint32_t *__restrict__ cnt_open, const uint32_t *__restrict__ offs_open,
+                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                        uint32_t *__restrict__ inst_gid, uint32_t *__restrict__ row_begin)
+{
+    constexpr int T = W * kWave;
+    __shared__ unsigned long long sh_m[T];
+    __shared__ uint32_t sh_off[T];
+    __shared__ uint32_t sh_wave[W];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = r0 + (int)blockIdx.x;
+    const uint32_t base = ctrl->chunk_base[c];
+    const bool nothing = ctrl->chunk_R[c] == 0u;
+    const uint32_t cnt = nothing ? 0u : cnt_open[r];
+    const uint32_t first = base + (nothing ? 0u : offs_open[r] - cnt);
+    if (threadIdx.x == 0) row_begin[r] = first;
+    if (cnt == 0u) return;
+    const uint32_t g = order[r];
+    const float4 cc = records[3 * (size_t)g + 2];
+    const TileRect t = unpack_rect(cc.z, cc.w);
+    const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0), ns = (total + kWave - 1) >> 6;
+    const uint32_t mb = mask_base(offs_full, r0, r, (uint32_t)total);
+    uint32_t carry = 0;
+    for (int s0 = 0; s0 < ns; s0 += T) {
+        // exclusive scan of the popcounts of steps [s0, s0 + T)
+        const int s = s0 + (int)threadIdx.x;
+        const unsigned long long m = s < ns ? masks[mb + (uint32_t)s] : 0ull;
+        const uint32_t pc = (uint32_t)__popcll(m);
+        uint32_t inc = pc;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t v = __shfl_up(inc, off);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) sh_wave[wv] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, wtot = 0;
+#pragma unroll
+        for (int i = 0; i < W; ++i) { const uint32_t v = sh_wave[i]; if (i < wv) wbase += v; wtot += v; }
+        sh_m[threadIdx.x] = m;
+        sh_off[threadIdx.x] = carry + wbase + inc - pc;
+        __syncthreads();
+        // expansion: one wave per step
+        const int nq = min(T, ns - s0);
+        for (int q = wv; q < nq; q += W) {
+            const unsigned long long mq = sh_m[q];
+            if ((mq >> lane) & 1ull) {
+                const int i = (s0 + q) * kWave + lane;
+                const int tx = t.x0 + i % w, ty = t.y0 + i / w;
+                const uint32_t slot = first + sh_off[q] + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
+                keys[slot] = (uint32_t)(ty * f.Gx + tx);
                 vals[slot] = slot;
                 inst_gid[slot] = g;
             }
-            emitted += (uint32_t)__popcll(m);
         }
+        carry += wtot;
+        __syncthreads();
+    }
+}
+
+// ---- variant B (chunks of many, small splats): count, then emit, the instances of the chunk's Gaussians: tiles of a Gaussian's rectangle that
+// are still open AND that its alpha >= 1/255 ellipse can reach (tile_may_contribute: exact culling, no pixel
+// changes).  One wave takes 64 consecutive depth ranks.
+//   Phase 1, one LANE per Gaussian: coalesced rank metadata, the record gathered into LDS (64 gathers in flight),
+//   quick reject of Gaussians whose rectangle holds no open tile (bit table staged in LDS).
+//   Phase 2, FLATTENED: the (Gaussian, tile) candidates of the 64 Gaussians form one list (prefix sum of the
+//   rectangle sizes); every step hands 64 consecutive candidates to the 64 lanes (binary search in the prefix),
+//   so a 2x2-tile splat costs 4 lanes, not a whole wave step, and a screen-filling one spreads over many steps.
+//   A Gaussian's candidates occupy consecutive lanes of a step: ballot + popcount over that lane segment give
+//   each accepted instance its ordinal; the segment's first lane carries the running count in LDS.
+constexpr int kBitsMaxWords = 2048;          // LDS copy of the open-bit table: up to 16 KB (e.g. 256 tile rows x 8 words)
+constexpr int kBinWaves = kBinBlock / kWave;
+
+__device__ __forceinline__ bool rect_has_open_tile(const TileRect &t, const unsigned long long *bits, int W64)
+{
+    if (t.x1 <= t.x0) return false;
+    const int w0 = t.x0 >> 6, w1 = (t.x1 - 1) >> 6;
+    for (int y = t.y0; y < t.y1; ++y)
+        for (int w = w0; w <= w1; ++w) {
+            unsigned long long m = ~0ull;
+            if (w == w0) m &= ~0ull << (t.x0 & 63);
+            if (w == w1) m &= ~0ull >> (63 - ((t.x1 - 1) & 63));
+            if (bits[y * W64 + w] & m) return true;
+        }
+    return false;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(kBinBlock) void k_bin_chunk(FrameK f, int c, int r0, int r1, const uint32_t *__restrict__ order,
+                                                         const float4 *__restrict__ records,
+                                                         const unsigned long long *__restrict__ open_bits,
+                                                         const Ctrl *__restrict__ ctrl, uint32_t *__restrict__ cnt_open,
+                                                         const uint32_t *__restrict__ offs_open, uint32_t *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals, uint32_t *__restrict__ inst_gid,
+                                                         uint32_t *__restrict__ row_begin)
+{
+    __shared__ unsigned long long sh_bits[kBitsMaxWords];
+    __shared__ float4 sh_a[kBinWaves][kWave];          // x, y, qA, qB
+    __shared__ float4 sh_b[kBinWaves][kWave];          // qC, lop, (x0 | y0 << 16), rectangle width
+    __shared__ uint32_t sh_end[kBinWaves][kWave];      // inclusive prefix of the rectangle sizes
+    __shared__ uint32_t sh_cnt[kBinWaves][kWave];      // accepted instances so far, per Gaussian
+    __shared__ uint32_t sh_first[kBinWaves][kWave];    // EMIT: first slot of the Gaussian
+    __shared__ uint32_t sh_gid[kBinWaves][kWave];      // EMIT: Gaussian index
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int W64 = (f.Gx + 63) >> 6, n_words = f.Gy * W64;
+    const bool in_lds = n_words <= kBitsMaxWords;
+    if (in_lds) {
+        for (int j = threadIdx.x; j < n_words; j += kBinBlock) sh_bits[j] = open_bits[j];
+        __syncthreads();
+    }
+    const unsigned long long *bits = in_lds ? sh_bits : open_bits;
+    const int r = r0 + ((blockIdx.x * kBinBlock + threadIdx.x) >> 6) * kWave + lane;       // this lane's depth rank
+    const bool mine = r < r1;
+    if (r - lane >= r1) return;                                                            // wave-uniform
+    // ---- phase 1
+    uint32_t total = 0, first = 0, g = 0;
+    bool alive = false;
+    if constexpr (EMIT) {
+        const uint32_t base = ctrl->chunk_base[c];
+        if (mine) {
+            const uint32_t cnt = ctrl->chunk_R[c] == 0u ? 0u : cnt_open[r];
+            first = base + (ctrl->chunk_R[c] == 0u ? 0u : offs_open[r] - cnt);
+            row_begin[r] = first;
+            alive = cnt != 0u;
+        }
+    } else {
+        alive = mine && !(c > 0 && ctrl->open_count == 0u);
+    }
+    if (alive) {
+        g = order[r];
+        const float4 cc = records[3 * (size_t)g + 2];
+        const TileRect t = unpack_rect(cc.z, cc.w);
+        if constexpr (!EMIT) alive = rect_has_open_tile(t, bits, W64);
+        if (alive) {
+            const float4 b = records[3 * (size_t)g + 1];
+            const int w = t.x1 - t.x0;
+            total = (uint32_t)(w * (t.y1 - t.y0));
+            sh_a[wv][lane] = records[3 * (size_t)g];
+            sh_b[wv][lane] = make_float4(b.x, b.y, __uint_as_float((uint32_t)t.x0 | ((uint32_t)t.y0 << 16)), __uint_as_float((uint32_t)w));
+        }
+    }
+    uint32_t end = total;                              // wave inclusive prefix sum
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const uint32_t v = __shfl_up(end, off);
+        if (lane >= off) end += v;
+    }
+    sh_end[wv][lane] = end;
+    sh_cnt[wv][lane] = 0;
+    if constexpr (EMIT) { sh_first[wv][lane] = first; sh_gid[wv][lane] = g; }
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)end, 63);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- phase 2
+    for (uint32_t k0 = 0; k0 < T; k0 += kWave) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        const bool valid = k < T;
+        int j = 0;                                     // smallest j with end[j] > k
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            if (sh_end[wv][j + step - 1] <= k) j += step;
+        if (!valid) j = 63;
+        const uint32_t ej = sh_end[wv][j];
+        const float4 a = sh_a[wv][j], b = sh_b[wv][j];
+        const uint32_t xy = __float_as_uint(b.z), w = __float_as_uint(b.w);
+        // candidate index inside its Gaussian: its rectangle holds (ej - start) tiles, start = end[j-1]
+        const uint32_t start = j > 0 ? sh_end[wv][j - 1] : 0u;
+        const uint32_t i = k - start;
+        bool want = false;
+        uint32_t tile = 0;
+        if (valid) {
+            const int tx = (int)(xy & 0xFFFFu) + (int)(i % w), ty = (int)(xy >> 16) + (int)(i / w);
+            tile = (uint32_t)(ty * f.Gx + tx);
+            if ((bits[ty * W64 + (tx >> 6)] >> (tx & 63)) & 1ull) {
+                float A, B, C, op;
+                unscale_conic(a.z, a.w, b.x, b.y, A, B, C, op);
+                want = tile_may_contribute(a.x, a.y, A, B, C, op, tx, ty);
+            }
+        }
+        const unsigned long long m = __ballot(want);
+        // this Gaussian's candidates sit on lanes [seg_lo, seg_hi) of this step
+        const uint32_t seg_lo = i < (uint32_t)lane ? (uint32_t)lane - i : 0u;
+        const uint32_t left = ej - k;                                      // candidates of j from this one on (>= 1)
+        const uint32_t seg_hi = min(64u, (uint32_t)lane + left);
+        const uint32_t before = sh_cnt[wv][j];
+        if constexpr (EMIT) {
+            if (want) {
+                const unsigned long long below = m & ((1ull << lane) - 1ull) & (~0ull << seg_lo);
+                const uint32_t slot = sh_first[wv][j] + before + (uint32_t)__popcll(below);
+                keys[slot] = tile;
+                vals[slot] = slot;
+                inst_gid[slot] = sh_gid[wv][j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (uint32_t)lane == seg_lo) {                            // one lane per Gaussian per step
+            const unsigned long long seg = (seg_hi >= 64u ? ~0ull : ((1ull << seg_hi) - 1ull)) & (~0ull << seg_lo);
+            sh_cnt[wv][j] = before + (uint32_t)__popcll(m & seg);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if constexpr (!EMIT) {
+        if (mine) cnt_open[r] = sh_cnt[wv][lane];
     }
 }
 
@@ -341,19 +537,34 @@ static int msb_plus1(uint32_t n)
     return b;
 }
 
-int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, GeomWS &gw, BinningWS &bw, ImageWS &iw,
+int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, uint64_t cand_before, GeomWS &gw, BinningWS &bw,
+                         ImageWS &iw,
                          int *sort_result, bool debug, hipStream_t s)
 {
     int rc;
     const int n = r1 - r0;
     if (n <= 0) return GSR_OK;
     const size_t Tn = (size_t)f.Gx * f.Gy;
+    // variant B packs the (Gaussian, tile) candidates of 64 Gaussians into full wave steps: right when rectangles are
+    // small; chunks of few large splats (the nearest ones) get a team of 1, 4 or 16 waves per Gaussian (variant A)
+    const uint64_t avg = n_max / (uint64_t)n;
+    const bool flat = avg < 24;
+    const int team = avg >= 1024 ? 16 : avg >= 96 ? 4 : 1;
+    const int bin_blocks = (n + kBinBlock - 1) / kBinBlock;      // B: 64 depth ranks per wave, 4 waves per block
+    // A's mask scratch: the idle half of the radix double buffer beyond everything earlier chunks can have written
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(bw.keys[1] + ((cand_before + 1) & ~(uint64_t)1));
     {
         ProfileScope prof("count_open", s);
-        int cblocks = (n + 3) / 4;                    // one wave per Gaussian per step
-        if (cblocks > 4096) cblocks = 4096;
-        hipLaunchKernelGGL(k_count_open, dim3(cblocks), dim3(kBinBlock), 0, s, f, r0, r1, gw.order, gw.records, iw.open,
-                           gw.ctrl, c, gw.cnt_open);
+#define GSR_CT(W)                                                                                                          \
+    hipLaunchKernelGGL(k_count_team<W>, dim3(n), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, iw.open_bits, gw.ctrl, \
+                       gw.offs_full, masks, gw.cnt_open)
+        if (flat)
+            hipLaunchKernelGGL(k_bin_chunk<false>, dim3(bin_blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records,
+                               iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);
+        else if (team == 16) GSR_CT(16);
+        else if (team == 4) GSR_CT(4);
+        else GSR_CT(1);
+#undef GSR_CT
         GSR_LAUNCH_CHECK("count_open", debug, s);
     }
     if ((rc = launch_scan_inclusive(gw.cnt_open + r0, gw.offs_open + r0, n, gw.scan_temp, &gw.ctrl->chunk_R[c],
@@ -361,10 +572,16 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
         return rc;
     {
         ProfileScope prof("emit", s);
-        int blocks = (n + 3) / 4;                     // one wave per Gaussian per step
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records, iw.open, gw.cnt_open,
-                           gw.offs_open, gw.ctrl, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);
+#define GSR_ET(W)                                                                                                          \
+    hipLaunchKernelGGL(k_emit_team<W>, dim3(n), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, gw.ctrl, gw.offs_full,  \
+                       masks, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin)
+        if (flat)
+            hipLaunchKernelGGL(k_bin_chunk<true>, dim3(bin_blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records,
+                               iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);
+        else if (team == 16) GSR_ET(16);
+        else if (team == 4) GSR_ET(4);
+        else GSR_ET(1);
+#undef GSR_ET
         GSR_LAUNCH_CHECK("emit", debug, s);
     }
     const int tile_bits = msb_plus1((uint32_t)(Tn ? Tn - 1 : 0));

@@ -97,6 +97,7 @@ struct ImageWS {                // O(N + Tn): the reference's imgBuffer
     int32_t *last_enc;          // [N]  (chunk + 1) << 26 | contributor position in that chunk's range
     uint2 *ranges;              // [GSR_MAX_CHUNKS][Tn]
     uint32_t *open;             // [Tn] 1 = tile still has an unsaturated pixel (0 outside the slab)
+    unsigned long long *open_bits;   // [Gy][ceil(Gx/64)] the same flags, one bit per tile (rebuilt at chunk boundaries)
     Ctrl *ctrl_scratch;         // stand-in control block for frames without a geometry workspace (P == 0)
     size_t total;
 };
@@ -131,7 +132,8 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
 int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
-int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, GeomWS &gw, BinningWS &bw, ImageWS &iw,
+int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, uint64_t cand_before, GeomWS &gw, BinningWS &bw,
+                         ImageWS &iw,
                          int *sort_result, bool debug, hipStream_t s);
 int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
