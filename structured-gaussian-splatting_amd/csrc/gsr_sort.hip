@@ -146,7 +146,7 @@ __device__ __forceinline__ void block_range(uint32_t n, int nblocks, uint32_t su
 
 template <typename K>
 __global__ __launch_bounds__(kRadixBlock) void k_radix_hist(const K *__restrict__ keys, const uint32_t *__restrict__ n_ptr,
-                                                            uint32_t n_host, const uint32_t *__restrict__ base_ptr, int shift,
+                                                            uint32_t n_host, const uint32_t *__restrict__ base_ptr, int shift, uint32_t dmask,
                                                             uint32_t subtile, uint32_t *__restrict__ table)
 {
     __shared__ uint32_t hist[kRadixBins];
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_hist(const K *__restrict_
     uint32_t lo, hi;
     block_range(n, gridDim.x, subtile, lo, hi);
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kRadixBlock) {
-        const uint32_t d = (uint32_t)(keys[i] >> shift) & 255u;
+        const uint32_t d = (uint32_t)(keys[i] >> shift) & dmask;
         const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
         const unsigned long long same = __ballot(d == d0);
         const unsigned long long act = __ballot(1);
@@ -196,7 +196,7 @@ template <typename K>
 __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                                K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                                const uint32_t *__restrict__ n_ptr, uint32_t n_host,
-                                                               const uint32_t *__restrict__ base_ptr, int shift,
+                                                               const uint32_t *__restrict__ base_ptr, int shift, uint32_t dmask,
                                                                const uint32_t *__restrict__ table,
                                                                const uint32_t *__restrict__ totals)
 {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
             const uint32_t idx = tile + w * (kWave * kRadixRounds) + r * kWave + lane;
             const bool valid = idx < hi;
             key[r] = valid ? keys_in[idx] : (K)0;
-            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
             unsigned long long peers = __ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
         for (int r = 0; r < kRadixRounds; ++r) {
             const uint32_t idx = tile + w * (kWave * kRadixRounds) + r * kWave + lane;
             if (idx < hi) {
-                const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+                const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
                 const uint32_t dst = offs[w][d] + local[r];
                 keys_out[dst] = key[r];
                 vals_out[dst] = vals_in[idx];
@@ -279,7 +279,7 @@ template <typename K>
 __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                                    K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                                    const uint32_t *__restrict__ n_ptr, uint32_t n_host,
-                                                                   const uint32_t *__restrict__ base_ptr, int shift,
+                                                                   const uint32_t *__restrict__ base_ptr, int shift, uint32_t dmask,
                                                                    const uint32_t *__restrict__ table,
                                                                    const uint32_t *__restrict__ totals)
 {
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__re
             const uint32_t idx = tile + w * (kWave * kBigRounds) + r * kWave + lane;
             const bool valid = idx < hi;
             key[r] = valid ? keys_in[idx] : (K)0;
-            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
             unsigned long long peers = __ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < 8; ++bit) {
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__re
         for (int r = 0; r < kBigRounds; ++r) {
             const uint32_t idx = tile + w * (kWave * kBigRounds) + r * kWave + lane;
             if (idx < hi) {
-                const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+                const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
                 const uint32_t p = offs[w][d] + local[r];
                 sk[p] = key[r];
                 sv[p] = vals_in[idx];
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__re
         const uint32_t count = min((uint32_t)kBigSubTile, hi - tile);
         for (uint32_t p = threadIdx.x; p < count; p += kRadixBlock) {
             const K kk = sk[p];
-            const uint32_t dst = delta[(uint32_t)(kk >> shift) & 255u] + p;
+            const uint32_t dst = delta[(uint32_t)(kk >> shift) & dmask] + p;
             keys_out[dst] = kk;
             vals_out[dst] = sv[p];
         }
@@ -389,17 +389,24 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
     uint32_t *table = (uint32_t *)temp;
     uint32_t *totals = (uint32_t *)((char *)temp + align_up((size_t)kRadixBins * kRadixMaxBlocks * 4));
     int cur = 0;
-    for (int shift = begin_bit; shift < end_bit; shift += 8) {
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], n_ptr, n_host, base_ptr, shift, subtile,
+    // digits: as few passes as 8-bit digits need, the key bits spread evenly over them (13 tile-id bits sort as
+    // 7 + 6, not 8 + 5: fewer bins in the first pass means longer contiguous runs in its scatter)
+    const int total_bits = end_bit - begin_bit, passes = (total_bits + 7) / 8;
+    int shift = begin_bit;
+    for (int p = 0; p < passes; ++p) {
+        const int left = end_bit - shift, bits = (left + (passes - p) - 1) / (passes - p);
+        const uint32_t dmask = (1u << bits) - 1u;
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], n_ptr, n_host, base_ptr, shift, dmask, subtile,
                            table);
         hipLaunchKernelGGL(k_radix_scan, dim3(kRadixBins), dim3(kRadixBlock), 0, s, table, B, totals);
         if (big)
             hipLaunchKernelGGL(k_radix_scatter_big<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
-                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, table, totals);
+                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, dmask, table, totals);
         else
             hipLaunchKernelGGL(k_radix_scatter<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
-                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, table, totals);
+                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, dmask, table, totals);
         cur ^= 1;
+        shift += bits;
     }
     *result = cur;
     GSR_LAUNCH_CHECK(name, debug, s);
