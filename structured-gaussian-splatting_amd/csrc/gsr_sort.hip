@@ -107,6 +107,34 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(uint32_t *__restrict__ 
         if (base + i < n) out[base + i] += add;
 }
 
+// short inputs (a chunk of a few thousand large splats): one block, one launch instead of three
+constexpr int kScanSmallMax = 8 * kScanTile;
+__global__ __launch_bounds__(kScanBlock) void k_scan_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n,
+                                                           uint32_t *__restrict__ grand_total, const uint32_t *__restrict__ acc_in,
+                                                           uint32_t *__restrict__ acc_out, uint32_t *__restrict__ overflow)
+{
+    __shared__ uint32_t sh_wave[kScanBlock / kWave];
+    uint32_t carry = 0;
+    unsigned long long wide = 0;
+    for (int t0 = 0; t0 < n; t0 += kScanTile) {
+        const int base = t0 + threadIdx.x * kScanItems;
+        uint32_t v[kScanItems], sum = 0;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; sum += v[i]; }
+        uint32_t total;
+        uint32_t run = carry + block_incl_scan(sum, sh_wave, &total) - sum;
+#pragma unroll
+        for (int i = 0; i < kScanItems; ++i) { run += v[i]; if (base + i < n) out[base + i] = run; }
+        wide += total;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        if (grand_total) *grand_total = carry;
+        if (acc_out) *acc_out = (acc_in ? *acc_in : 0u) + carry;
+        if (overflow) *overflow = wide > 0xFFFFFFFFull ? 1u : 0u;
+    }
+}
+
 size_t scan_temp_bytes(int n) { return align_up((size_t)((n + kScanTile - 1) / kScanTile + 1) * 4); }
 
 // out[i] = in[0] + ... + in[i]; optional *grand_total (device) = sum of all.
@@ -120,6 +148,11 @@ int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, 
         return GSR_OK;
     }
     ProfileScope prof(name, s);
+    if (n <= kScanSmallMax) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, s, in, out, n, grand_total, acc_in, acc_out, overflow);
+        GSR_LAUNCH_CHECK(name, debug, s);
+        return GSR_OK;
+    }
     const int nb = (n + kScanTile - 1) / kScanTile;
     uint32_t *sums = (uint32_t *)temp;
     hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kScanBlock), 0, s, in, out, sums, n);
