@@ -124,6 +124,25 @@ class _Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
+    def max_int_deferred(self, value: int, device):
+        """MAX over ranks of a host integer, started now and read later: returns a callable.  On RCCL the reduced word
+        is copied to pinned host memory behind the collective and an event is recorded, so reading it in the backward
+        does not make the host wait for the stream (a blocking .item() there drains the whole forward + loss)."""
+        if self.gloo:
+            v = self.max_int(value, device)
+            return lambda: v
+        t = torch.tensor([int(value)], dtype=torch.int64).pin_memory().to(device, non_blocking=True)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        host = torch.empty(1, dtype=torch.int64).pin_memory()
+        host.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+
+        def read():
+            ev.synchronize()
+            return int(host[0])
+        return read
+
     def reduce_scatter_sum(self, full: torch.Tensor) -> torch.Tensor:
         """[world * n, ...] per rank -> [n, ...] = sum over ranks of this rank's block."""
         n = full.shape[0] // self.world
@@ -160,6 +179,12 @@ class _ShardedRasterize(torch.autograd.Function):
             if b_px > a_px and r != comm.rank:
                 full[:, a_px:b_px] = gathered[r, :, :b_px - a_px]
         ctx.frame, ctx.shard, ctx.rs = frame, shard, rs
+        ctx.n_max = None
+        if shard.backward_mode == "allreduce_screen" and any(ctx.needs_input_grad[:8]):
+            # longest binned depth prefix over the ranks: sizes the backward's gradient exchange; started here so
+            # that the backward finds it on the host without a stream drain
+            order, n_mine = backend.binned_prefix(frame)
+            ctx.n_max = (order, comm.max_int_deferred(n_mine, means3D.device) if order is not None else None)
         ctx.shapes = (means2D.shape, opacities.shape)
         ctx.mark_non_differentiable(radii)
         return full, radii
@@ -174,8 +199,12 @@ class _ShardedRasterize(torch.autograd.Function):
         partial = backend.backward_screen(frame, grad_color)                       # [P, 12]
         if shard.backward_mode == "allreduce_screen":
             # (2) sum over slabs; only the binned prefix of the depth order can be non-zero on any rank
-            order, n_mine = backend.binned_prefix(frame)
-            n_max = comm.max_int(n_mine, partial.device)
+            if ctx.n_max is not None:
+                order, read = ctx.n_max
+                n_max = read() if read is not None else P
+            else:
+                order, n_mine = backend.binned_prefix(frame)
+                n_max = comm.max_int(n_mine, partial.device)
             if order is None or n_max >= P:
                 screen = comm.all_reduce_sum(partial.contiguous())
             else:
