@@ -285,9 +285,21 @@ def _train_loop(workload, iters, dev, fused):
     opt = replace(OptimizationDefaults(), densify_from_iter=0)
     gm.training_setup(opt)
     warm = min(20, iters // 4)
+    # one-time library initialisation (rocBLAS for the split's bmm, torch's RNG / index kernels: ~0.5 s on first use)
+    # on a throw-away 2000-Gaussian model, so that the timed loop's first densification costs what every later one costs
+    tiny = GaussianModel(0)
+    tiny.adopt_scene(S.make_scene(2000, 64, 64, 0, 1), device=dev)
+    tiny.training_setup(opt)
+    tiny.xyz_gradient_accum += 1.0
+    tiny.denom += 1.0
+    with torch.no_grad():
+        tiny.densify_and_prune(opt.densify_grad_threshold, 0.005, 6.0, None)
+    del tiny
     pipe = Pipe()
     pipe.fused_activations = bool(fused)
     train(gm, cams, targets, opt, pipe, bg, iterations=warm, scene_extent=6.0)
+    with torch.no_grad():       # warm-up includes one full-size densification: the allocator has seen the grown tensors
+        gm.densify_and_prune(opt.densify_grad_threshold, 0.005, 6.0, None)
     torch.cuda.synchronize(dev)
     n0 = gm._xyz.shape[0]
     t0 = time.perf_counter()

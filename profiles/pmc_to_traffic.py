@@ -23,7 +23,8 @@ NAMES = {
     "gsr::k_render_bwd": "render_bwd", "gsr::k_render_fwd": "render_fwd", "void gsr::k_geom_bwd<": "geom_bwd",
     "void gsr::k_geom_bwd_sparse<": "geom_bwd", "void gsr::k_preprocess<": "preprocess",
     "void gsr::k_reduce_rows<": "reduce_rows", "gsr::k_loss_fwd": "loss_fwd", "gsr::k_loss_bwd": "loss_bwd",
-    "gsr::k_emit": "emit", "gsr::k_count_open": "count_open", "gsr::k_ranges": "ranges",
+    "void gsr::k_emit_team<": "emit", "void gsr::k_count_team<": "count_open", "void gsr::k_bin_chunk<false>": "count_open",
+    "void gsr::k_bin_chunk<true>": "emit", "gsr::k_ranges": "ranges",
 }
 SKIP_FIRST = 3
 
