@@ -82,6 +82,8 @@ __device__ __forceinline__ float bcast_lane63(float v)
 }
 
 constexpr int kStrips = 4;
+constexpr int kPairs = kStrips / 2;
+typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 operand (two pixels of one lane)
 
 // ------------------------------------------------------------------------------------------- K6
 // One launch per depth chunk.  A tile's wave resumes the pixels' state (T, colour, last contributor) where
@@ -233,25 +235,28 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
     const size_t N = (size_t)f.W * f.H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-    float fy[kStrips], T[kStrips], bgterm[kStrips], dpr[kStrips], dpg[kStrips], dpb[kStrips];
-    float ar[kStrips], ag[kStrips], ab[kStrips];               // colour behind the current splat, per pixel
+    // Per-pixel state in PAIRS of strips (k = 2p, 2p + 1) as 2-vectors: the arithmetic below then compiles to packed
+    // fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), two pixels per VALU issue.
+    v2f fy[kPairs], T[kPairs], bgterm[kPairs], dpr[kPairs], dpg[kPairs], dpb[kPairs];
+    v2f ar[kPairs], ag[kPairs], ab[kPairs];                    // colour behind the current splat, per pixel
     int c_last[kStrips], n_last[kStrips];
 #pragma unroll
     for (int k = 0; k < kStrips; ++k) {
         const int py = py0 + 4 * k;
-        fy[k] = (float)py;
         const bool inside = px < f.W && py < f.H;
         const size_t pix = inside ? (size_t)py * f.W + px : 0;
-        T[k] = inside ? fabsf(T_state[pix]) : 0.f;
+        const float Tk = inside ? fabsf(T_state[pix]) : 0.f;
         const int enc = inside ? last_enc[pix] : 0;
         c_last[k] = (enc >> kLastShift) - 1;                              // -1: no contributor at all
         n_last[k] = enc & ((1 << kLastShift) - 1);
-        dpr[k] = inside ? dL_dpix[pix] : 0.f;
-        dpg[k] = inside ? dL_dpix[N + pix] : 0.f;
-        dpb[k] = inside ? dL_dpix[2 * N + pix] : 0.f;
-        bgterm[k] = -T[k] * (bg0 * dpr[k] + bg1 * dpg[k] + bg2 * dpb[k]);   // -T_final * <bg, dL/dpix>
-        ar[k] = ag[k] = ab[k] = 0.f;
+        const float r_ = inside ? dL_dpix[pix] : 0.f, g_ = inside ? dL_dpix[N + pix] : 0.f, b_ = inside ? dL_dpix[2 * N + pix] : 0.f;
+        fy[k >> 1][k & 1] = (float)py;
+        T[k >> 1][k & 1] = Tk;
+        dpr[k >> 1][k & 1] = r_; dpg[k >> 1][k & 1] = g_; dpb[k >> 1][k & 1] = b_;
+        bgterm[k >> 1][k & 1] = -Tk * (bg0 * r_ + bg1 * g_ + bg2 * b_);     // -T_final * <bg, dL/dpix>
     }
+#pragma unroll
+    for (int p = 0; p < kPairs; ++p) { ar[p] = v2f{0.f, 0.f}; ag[p] = ar[p]; ab[p] = ar[p]; }
     const float half_w = 0.5f * (float)f.W, half_h = 0.5f * (float)f.H;
 
     for (int c = chunks_run - 1; c >= 0; --c) {
@@ -295,42 +300,49 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
                     float cA, cB, cC, opac;                                      // the unscaled conic / opacity (per splat)
                     unscale_conic(a.z, a.w, b.x, b.y, cA, cB, cC, opac);
                     const float inv_op = fast_rcp(opac);
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f;
+                    v2f S0 = {0.f, 0.f}, S1 = S0, S2 = S0, S3 = S0, S4 = S0, S5 = S0, S6 = S0, S7 = S0, S8 = S0;
                     bool any_valid = false;
 #pragma unroll
-                    for (int k = 0; k < kStrips; ++k) {
-                        const float dy = a.y - fy[k];
-                        const float lp = (b.x * dy + bx) * dy + axx;
-                        const float araw = __builtin_amdgcn_exp2f(fminf(lp, b.y));   // = op * G; power > 0 lanes are rejected
-                        const float G = araw * inv_op;
-                        const float alpha = fminf((float)GSR_ALPHA_MAX, araw);
-                        const bool valid = (pos < limit[k]) && !(lp > b.y) && !(alpha < (float)GSR_ALPHA_MIN);
-                        any_valid = any_valid || valid;
-                        // Rejected pixels run the same arithmetic with alpha = 0 and G = 0: T, the colour behind and
-                        // every partial sum then stay exactly unchanged, so only these two values need a select.
-                        const float ae = valid ? alpha : 0.f;
-                        const float Ge = valid ? G : 0.f;
-                        const float inv1ma = fast_rcp(1.f - ae);
-                        const float Tn_ = T[k] * inv1ma;                      // T before this splat
-                        const float w = ae * Tn_;                             // d colour / d rgb
+                    for (int p = 0; p < kPairs; ++p) {
+                        const v2f dy = a.y - fy[p];
+                        const v2f lp = (b.x * dy + bx) * dy + axx;
+                        v2f araw, ae, Ge;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int k = 2 * p + e;
+                            araw[e] = __builtin_amdgcn_exp2f(fminf(lp[e], b.y));     // = op * G; power > 0 lanes are rejected
+                            const float alpha = fminf((float)GSR_ALPHA_MAX, araw[e]);
+                            const bool valid = (pos < limit[k]) && !(lp[e] > b.y) && !(alpha < (float)GSR_ALPHA_MIN);
+                            any_valid = any_valid || valid;
+                            // Rejected pixels run the same arithmetic with alpha = 0 and G = 0: T, the colour behind and
+                            // every partial sum then stay exactly unchanged, so only these two values need a select.
+                            ae[e] = valid ? alpha : 0.f;
+                            Ge[e] = valid ? araw[e] * inv_op : 0.f;
+                        }
+                        const v2f one_m = 1.f - ae;
+                        const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
+                        const v2f Tn_ = T[p] * inv1ma;                        // T before this splat
+                        const v2f w = ae * Tn_;                               // d colour / d rgb
                         // colour behind this splat (A.9's accum_rec), updated as soon as the splat is processed:
                         // B <- alpha c + (1 - alpha) B
-                        const float dr = b.z - ar[k], dg = b.w - ag[k], db = cb - ab[k];
-                        float dL_dalpha = dr * dpr[k] + dg * dpg[k] + db * dpb[k];
-                        ar[k] += ae * dr; ag[k] += ae * dg; ab[k] += ae * db;
-                        dL_dalpha = dL_dalpha * Tn_ + bgterm[k] * inv1ma;
-                        const float gdx = Ge * dx, gdy = Ge * dy;
-                        const float tG = opac * dL_dalpha;                    // dL/dG (times G through gdx, gdy)
-                        const float tx = tG * gdx, ty = tG * gdy;
-                        s0 -= tx * cA + ty * cB;                              // dL/dG * dG/ddelx
-                        s1 -= ty * cC + tx * cB;
-                        s2 += tx * dx;
-                        s3 += tx * dy;
-                        s4 += ty * dy;
-                        s5 += Ge * dL_dalpha;
-                        s6 += w * dpr[k]; s7 += w * dpg[k]; s8 += w * dpb[k];
-                        T[k] = Tn_;
+                        const v2f dr = b.z - ar[p], dg = b.w - ag[p], db = cb - ab[p];
+                        v2f dL_dalpha = dr * dpr[p] + dg * dpg[p] + db * dpb[p];
+                        ar[p] += ae * dr; ag[p] += ae * dg; ab[p] += ae * db;
+                        dL_dalpha = dL_dalpha * Tn_ + bgterm[p] * inv1ma;
+                        const v2f gdx = Ge * dx, gdy = Ge * dy;
+                        const v2f tG = opac * dL_dalpha;                      // dL/dG (times G through gdx, gdy)
+                        const v2f tx = tG * gdx, ty = tG * gdy;
+                        S0 -= tx * cA + ty * cB;                              // dL/dG * dG/ddelx
+                        S1 -= ty * cC + tx * cB;
+                        S2 += tx * dx;
+                        S3 += tx * dy;
+                        S4 += ty * dy;
+                        S5 += Ge * dL_dalpha;
+                        S6 += w * dpr[p]; S7 += w * dpg[p]; S8 += w * dpb[p];
+                        T[p] = Tn_;
                     }
+                    float s0 = S0[0] + S0[1], s1 = S1[0] + S1[1], s2 = S2[0] + S2[1], s3 = S3[0] + S3[1], s4 = S4[0] + S4[1],
+                          s5 = S5[0] + S5[1], s6 = S6[0] + S6[1], s7 = S7[0] + S7[1], s8 = S8[0] + S8[1];
                     if (__ballot(any_valid) == 0ull) continue;               // nobody accepted this splat: row stays 0
                     wave_sum9_to_lane63(s0, s1, s2, s3, s4, s5, s6, s7, s8);
                     // lane 63 holds the nine totals: it stores the splat's row itself (three 16-B stores)
