@@ -748,3 +748,20 @@ def test_native_densification_stats_equal_masked_torch_ops():
     torch.cuda.synchronize()
     assert torch.equal(gm.max_radii2D, ref["mr"]) and torch.equal(gm.denom, ref["den"])
     assert torch.allclose(gm.xyz_gradient_accum, ref["acc"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("scale_lo,scale_hi,label", [(0.5, 2.0, "teams of 16 waves"), (0.08, 0.3, "teams of 4 waves")])
+def test_chunks_of_few_large_splats(scale_lo, scale_hi, label):
+    """Count/emit variant A with wide teams (mean rectangle >= 1024 tiles -> 16 waves per Gaussian, >= 96 -> 4): a few
+    hundred screen-filling splats at 1280x720 (3600 tiles).  Forward, intermediates and backward against the oracle."""
+    W, H = 1280, 720
+    scene = S.make_scene(300, W, H, 1, 301, scale_lo=scale_lo, scale_hi=scale_hi)
+    kw = raster_kwargs(scene, S.make_camera(W, H))
+    fr64 = oracle.rasterize(dtype=np.float64, fragile_eps=2e-5, parallel=True, **kw)
+    vis = fr64.radii > 0
+    mean_rect = fr64.tiles_touched[vis].mean()
+    assert mean_rect >= (1024 if "16" in label else 96), mean_rect
+    gimg = S.make_grad_image(W, H, 12).numpy()
+    color, radii, grads = _run_gpu(kw, gimg)
+    _check_forward(kw, fr64, color, radii)
+    _check_grads(fr64, fr64.backward(gimg), grads, ["means3D", "means2D", "opacities", "shs", "scales", "rotations"])
