@@ -16,9 +16,11 @@ constexpr int kGeomBlock = 256;
 template <int DEG, bool RAW>
 struct GaussIn {
     float p[3], sc[3], q[4], cv[6], opacity;
-    float shl[RAW ? 3 * (DEG + 1) * (DEG + 1) : 1];
-    const float *sh;          // this Gaussian's [K,3] coefficients as preprocess_one / geom_backward_one read them
+    float shl[RAW ? 3 * (DEG + 1) * (DEG + 1) : 1];     // RAW: the [K,3] coefficients, features_dc ++ features_rest
+    const float *sh_global;   // !RAW: this Gaussian's [M,3] coefficients in the shs tensor (or null)
     RawAct act;
+    // what preprocess_one / geom_backward_one read; no pointer member aliases shl, so the array stays in registers
+    __device__ __forceinline__ const float *sh() const { if constexpr (RAW) return shl; else return sh_global; }
 };
 
 template <int DEG, bool RAW>
@@ -51,7 +53,7 @@ __device__ __forceinline__ void load_gaussian(int i, int M, const float *__restr
 #pragma unroll
             for (int k = 0; k < 3 * K; ++k) in.shl[k] = 0.f;
         }
-        in.sh = in.shl;
+        in.sh_global = nullptr;
     } else {
         if (covpre) {
 #pragma unroll
@@ -62,7 +64,7 @@ __device__ __forceinline__ void load_gaussian(int i, int M, const float *__restr
             in.q[0] = qq.x; in.q[1] = qq.y; in.q[2] = qq.z; in.q[3] = qq.w;
         }
         in.opacity = opac ? opac[i] : 0.f;
-        in.sh = shs ? shs + (size_t)i * M * 3 : nullptr;
+        in.sh_global = shs ? shs + (size_t)i * M * 3 : nullptr;
     }
 }
 
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
     const float p0[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
     load_gaussian<DEG, RAW>(i, f.M, means, scales, rots, covpre, opac, shs, shs_rest, in_frustum(p0, V), in);
     PreOut o;
-    preprocess_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.opacity, in.sh,
+    preprocess_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.opacity, in.sh(),
                         (!RAW && colpre) ? colpre + 3 * (size_t)i : nullptr, o);
     radii[i] = o.radius;
     tiles[i] = o.tiles;
@@ -158,8 +160,14 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
     for (int k = 0; k < 4; ++k) g.drot[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) g.dcov[k] = 0.f;
-    float dsh[48];
-    const int K = (DEG + 1) * (DEG + 1);
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    // dL/dsh leaves through LDS: every lane owns one staging row of 3M (+1 pad) floats; geom_backward_one writes the
+    // 3K live entries straight into it, the rest is zero-filled, and the wave then stores its 64 rows as one
+    // contiguous, lane-coalesced run
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rowf = 3 * M;                                       // floats per Gaussian incl. the DC triple
+    float *my_row = sh_stage + wv * (64 * 49) + lane * (rowf + 1);
+    const bool sh_wanted = shs && (out.shs || (RAW && out.shs_rest));
     // A Gaussian that no pixel accepted (occluded behind saturated tiles, or just too faint everywhere) has an
     // all-zero screen-space gradient; every output of A.10 is linear in it, so its rows are exact zeros and none
     // of its inputs need to be read.  In depth-complex scenes that is the vast majority of the visible set.
@@ -178,8 +186,8 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
         GaussIn<DEG, RAW> in;
         load_gaussian<DEG, RAW>(i, M, means, scales, rots, covpre, opac, shs, shs_rest, true, in);
         const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
-        geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh, has_colpre != 0,
-                               clamped[i], sg, g, (shs && (out.shs || (RAW && out.shs_rest))) ? dsh : nullptr);
+        geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh(), has_colpre != 0,
+                               clamped[i], sg, g, my_row, sh_wanted);
         if constexpr (RAW) activate_raw_backward(in.act, g);
     }
     if (!in_range) { /* lanes past the end only help with the cooperative SH store below */ }
@@ -197,35 +205,34 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
         for (int k = 0; k < 6; ++k) out.cov3D_precomp[6 * (size_t)i + k] = g.dcov[k];
     }
     }
-    if constexpr (RAW) {
-        if (in_range && out.shs) {
-            out.shs[3 * (size_t)i] = live ? dsh[0] : 0.f; out.shs[3 * (size_t)i + 1] = live ? dsh[1] : 0.f;
-            out.shs[3 * (size_t)i + 2] = live ? dsh[2] : 0.f;
-        }
-    }
-    float *sh_out = RAW ? out.shs_rest : out.shs;
-    const int row = RAW ? 3 * (M - 1) : 3 * M;                    // floats per Gaussian in sh_out
-    constexpr int off = RAW ? 3 : 0;                              // first dsh entry that belongs to sh_out
-    if (sh_out && shs && row > 0) {
-        // dL/dsh rows are `row` floats per Gaussian: a wave's 64 rows form one contiguous run, written with
-        // lane-contiguous stores.  Fast path (no live Gaussian in the wave): zeros straight from registers.
-        // Otherwise the rows go through LDS (row stride row+1 dwords: conflict-free transposition).
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (sh_wanted && rowf > 0) {
         const int wave_first = i - lane;                           // first Gaussian of this wave
         const int n_rows = min(64, g1 - wave_first);
-        float *dst = sh_out + (size_t)wave_first * row;
-        const int total = n_rows * row;
-        if (__ballot(live) == 0ull) {
-            for (int e = lane; e < total; e += 64) dst[e] = 0.f;
-        } else {
-            float *stage = sh_stage + w * (64 * 49);
+        const bool any_live = __ballot(live) != 0ull;
+        if (any_live) {
             const int nlive = live ? 3 * K : 0;
-#pragma unroll
-            for (int k = 0; k < 48 - off; ++k)
-                if (k < row) stage[lane * (row + 1) + k] = (k + off) < nlive ? dsh[k + off] : 0.f;
+            for (int k = nlive; k < rowf; ++k) my_row[k] = 0.f;    // rows of dead lanes, coefficients above the active degree
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            for (int e = lane; e < total; e += 64) dst[e] = stage[(e / row) * (row + 1) + e % row];
+        }
+        const float *stage = sh_stage + wv * (64 * 49);
+        if constexpr (RAW) {
+            if (in_range && out.shs) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) out.shs[3 * (size_t)i + ch] = any_live ? my_row[ch] : 0.f;
+            }
+            const int row = rowf - 3;                              // _features_rest: floats per Gaussian
+            if (out.shs_rest && row > 0 && n_rows > 0) {
+                float *dst = out.shs_rest + (size_t)wave_first * row;
+                const int total = n_rows * row;
+                if (!any_live) { for (int e = lane; e < total; e += 64) dst[e] = 0.f; }
+                else { for (int e = lane; e < total; e += 64) dst[e] = stage[(e / row) * (rowf + 1) + 3 + e % row]; }
+            }
+        } else if (n_rows > 0) {
+            float *dst = out.shs + (size_t)wave_first * rowf;
+            const int total = n_rows * rowf;
+            if (!any_live) { for (int e = lane; e < total; e += 64) dst[e] = 0.f; }
+            else { for (int e = lane; e < total; e += 64) dst[e] = stage[(e / rowf) * (rowf + 1) + e % rowf]; }
         }
     }
 }
@@ -261,9 +268,9 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
     load_gaussian<DEG, RAW>(i, M, means, scales, rots, covpre, opac, shs, shs_rest, true, in);
     const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
     GeomGrad g;
-    float dsh[48];
-    geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh, has_colpre != 0, clamped[i],
-                           sg, g, (shs && (out.shs || (RAW && out.shs_rest))) ? dsh : nullptr);
+    float dsh[3 * (DEG + 1) * (DEG + 1)];          // constant indices only: stays in registers
+    geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh(), has_colpre != 0, clamped[i],
+                           sg, g, dsh, shs != nullptr);
     if constexpr (RAW) activate_raw_backward(in.act, g);
     if (out.means3D) { out.means3D[3 * i] = g.dmean[0]; out.means3D[3 * i + 1] = g.dmean[1]; out.means3D[3 * i + 2] = g.dmean[2]; }
     if (out.means2D) { out.means2D[3 * i] = g.dmean2D[0]; out.means2D[3 * i + 1] = g.dmean2D[1]; }
@@ -283,14 +290,13 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
         if (out.shs_rest) {
             float *dst = out.shs_rest + (size_t)i * (M - 1) * 3;
 #pragma unroll
-            for (int k = 3; k < 48; ++k)
-                if (k < K3) dst[k - 3] = dsh[k];
+            for (int k = 3; k < K3; ++k) dst[k - 3] = dsh[k];
         }
     } else if (out.shs && shs) {
         float *dst = out.shs + (size_t)i * M * 3;
 #pragma unroll
-        for (int k = 0; k < 48; ++k)
-            if (k < K3 && k < 3 * M) dst[k] = dsh[k];
+        for (int k = 0; k < K3; ++k)
+            if (k < 3 * M) dst[k] = dsh[k];
     }
 }
 

@@ -339,13 +339,14 @@ struct GeomGrad {
 };
 
 // ---- A.10 for one visible Gaussian.  sg = (dmean2D.x, dmean2D.y, gA, gB, gC, dopacity, drgb[3]).
-// dsh (this Gaussian's [M,3] output, or null) receives basis_k * dRGB for k < K; the caller zeroes
-// k >= K.  clamped: bit c set <=> channel c was clamped in the forward.
+// dsh (this Gaussian's [K,3] row, written when want_dsh) receives basis_k * dRGB for k < K; the caller zeroes
+// k >= K.  It may point anywhere (registers, an LDS staging row, the output tensor itself) but never depends on a
+// run-time select, so that a register array stays in registers.  clamped: bit c set <=> channel c was clamped.
 template <int DEG = -1>
 GSR_HD void geom_backward_one(const FrameK &f, const float *V, const float *PV, const float *campos,
                               const float p[3], const float *scale, const float *quat, const float *covpre,
                               const float *sh, bool has_colpre, unsigned clamped, const float sg[9],
-                              GeomGrad &g, float *dsh)
+                              GeomGrad &g, float *dsh, bool want_dsh = true)
 {
     float pv[3];
     pv[0] = p[0] * V[0] + p[1] * V[4] + p[2] * V[8] + V[12];
@@ -424,7 +425,7 @@ GSR_HD void geom_backward_one(const FrameK &f, const float *V, const float *PV, 
 #endif
             for (int k = 0; k < K; ++k) {
                 const float c = sh[3 * k + ch] * dRGB;
-                if (dsh) dsh[3 * k + ch] = bas[k] * dRGB;
+                if (want_dsh) dsh[3 * k + ch] = bas[k] * dRGB;
                 ddx += bx[k] * c; ddy += by[k] * c; ddz += bz[k] * c;
             }
         }

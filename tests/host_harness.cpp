@@ -51,7 +51,7 @@ extern "C" void hh_geom_backward(int P, int D, int M, int W, int H, float tanfov
         GeomGrad g;
         geom_backward_one(f, V, PV, campos, means + 3 * i, scales ? scales + 3 * i : nullptr, rots ? rots + 4 * i : nullptr,
                           covpre ? covpre + 6 * i : nullptr, shs ? shs + (size_t)i * M * 3 : nullptr, has_colpre != 0,
-                          clamped[i], screen9 + 9 * i, g, (shs && dsh) ? dsh + (size_t)i * M * 3 : nullptr);
+                          clamped[i], screen9 + 9 * i, g, (shs && dsh) ? dsh + (size_t)i * M * 3 : nullptr, shs && dsh);
         for (int k = 0; k < 3; ++k) { dmeans3D[3 * i + k] = g.dmean[k]; dcolors[3 * i + k] = g.dcolor[k]; dscales[3 * i + k] = g.dscale[k]; }
         dmeans2D[3 * i] = g.dmean2D[0]; dmeans2D[3 * i + 1] = g.dmean2D[1]; dmeans2D[3 * i + 2] = 0.f;
         dopac[i] = g.dopacity;
