@@ -45,19 +45,26 @@ __device__ __forceinline__ float block_sum(float v, float *sh /*[4]*/)
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// Register-blocked separable window.  Row pass: 168 threads, each one row x 8 adjacent columns (18 staged values of a
+// and of b -> 8 x 5 moments); column pass: 256 threads, each one column x 4 adjacent rows (14 row-filtered values per
+// moment).  ~115 LDS reads per thread instead of ~350 for one-output-at-a-time.
+constexpr int kLP = kLI + 2;            // 44: staged row pitch (16-byte aligned rows)
+constexpr int kRowW = 8;                // outputs per thread in the row pass
+constexpr int kRowItems = kLI * (kLT / kRowW);     // 168
+constexpr int kColH = 4;                // outputs per thread in the column pass
+
 __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, const float *__restrict__ a, const float *__restrict__ b,
                                                       float *__restrict__ d_mu, float *__restrict__ d_eaa, float *__restrict__ d_eab,
                                                       float *__restrict__ partial_ssim, float *__restrict__ partial_l1)
 {
     // LDS is used twice: first the staged tile + halo of a and b, then (after every thread holds its row-filtered
-    // values in registers) the five row-filtered moment planes OVER the same bytes: 27.7 KB per block instead of
-    // 42 KB, i.e. 5 resident blocks per CU instead of 3.
-    constexpr int kStageFloats = 2 * kLI * (kLI + 1);
+    // values in registers) the five row-filtered moment planes OVER the same bytes.
+    constexpr int kStageFloats = 2 * kLI * kLP;
     constexpr int kHzFloats = 5 * kLI * (kLT + 1);
-    __shared__ float lds[kHzFloats > kStageFloats ? kHzFloats : kStageFloats];
+    __shared__ __attribute__((aligned(16))) float lds[kHzFloats > kStageFloats ? kHzFloats : kStageFloats];
     __shared__ float red[4];
-    float (*sa)[kLI + 1] = reinterpret_cast<float (*)[kLI + 1]>(lds);
-    float (*sb)[kLI + 1] = reinterpret_cast<float (*)[kLI + 1]>(lds + kLI * (kLI + 1));
+    float (*sa)[kLP] = reinterpret_cast<float (*)[kLP]>(lds);
+    float (*sb)[kLP] = reinterpret_cast<float (*)[kLP]>(lds + kLI * kLP);
     float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
     const int ch = blockIdx.z, x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const size_t plane = (size_t)ch * H * W;
@@ -69,64 +76,72 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
         sb[r][c] = in ? b[plane + (size_t)y * W + x] : 0.f;
     }
     __syncthreads();
-    // this thread's four output pixels: centre values for the L1 term, before the staging area is overwritten
-    float ca[(kLT * kLT) / kLBlock], cbv[(kLT * kLT) / kLBlock];
+    // column-pass mapping of this thread: column cc, rows rr0 .. rr0 + 3; centre values for the L1 term are read now,
+    // before the staging area is overwritten
+    const int cc = threadIdx.x % kLT, rr0 = (threadIdx.x / kLT) * kColH;
+    float ca[kColH], cbv[kColH];
 #pragma unroll
-    for (int k = 0; k < (kLT * kLT) / kLBlock; ++k) {
-        const int idx = threadIdx.x + k * kLBlock;
-        ca[k] = sa[idx / kLT + kLH][idx % kLT + kLH];
-        cbv[k] = sb[idx / kLT + kLH][idx % kLT + kLH];
-    }
-    constexpr int kHzIters = (kLI * kLT + kLBlock - 1) / kLBlock;       // 6
-    float m0[kHzIters], m1[kHzIters], m2[kHzIters], m3[kHzIters], m4[kHzIters];
+    for (int k = 0; k < kColH; ++k) { ca[k] = sa[rr0 + k + kLH][cc + kLH]; cbv[k] = sb[rr0 + k + kLH][cc + kLH]; }
+    // row pass
+    float m[5][kRowW];
+    const bool row_item = threadIdx.x < kRowItems;
+    const int hr = threadIdx.x / (kLT / kRowW), hc0 = (threadIdx.x % (kLT / kRowW)) * kRowW;
+    if (row_item) {
+        float va[kRowW + 10], vb[kRowW + 10];
 #pragma unroll
-    for (int it = 0; it < kHzIters; ++it) {
-        const int idx = threadIdx.x + it * kLBlock;
-        m0[it] = m1[it] = m2[it] = m3[it] = m4[it] = 0.f;
-        if (idx < kLI * kLT) {
-            const int r = idx / kLT, c = idx % kLT;
+        for (int i = 0; i < kRowW + 10; ++i) { va[i] = sa[hr][hc0 + i]; vb[i] = sb[hr][hc0 + i]; }
+#pragma unroll
+        for (int o = 0; o < kRowW; ++o) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
 #pragma unroll
             for (int i = 0; i < 11; ++i) {
-                const float g = win.g[i], va = sa[r][c + i], vb = sb[r][c + i];
-                m0[it] += g * va; m1[it] += g * vb; m2[it] += g * va * va; m3[it] += g * vb * vb; m4[it] += g * va * vb;
+                const float g = win.g[i], x = va[o + i], y = vb[o + i];
+                const float gx = g * x, gy = g * y;
+                s0 += gx; s1 += gy; s2 += gx * x; s3 += gy * y; s4 += gx * y;
             }
+            m[0][o] = s0; m[1][o] = s1; m[2][o] = s2; m[3][o] = s3; m[4][o] = s4;
         }
     }
     __syncthreads();
+    if (row_item) {
 #pragma unroll
-    for (int it = 0; it < kHzIters; ++it) {
-        const int idx = threadIdx.x + it * kLBlock;
-        if (idx < kLI * kLT) {
-            const int r = idx / kLT, c = idx % kLT;
-            hz[0][r][c] = m0[it]; hz[1][r][c] = m1[it]; hz[2][r][c] = m2[it]; hz[3][r][c] = m3[it]; hz[4][r][c] = m4[it];
-        }
+        for (int pl = 0; pl < 5; ++pl)
+#pragma unroll
+            for (int o = 0; o < kRowW; ++o) hz[pl][hr][hc0 + o] = m[pl][o];
     }
     __syncthreads();
+    // column pass
+    float acc[5][kColH];
+#pragma unroll
+    for (int pl = 0; pl < 5; ++pl) {
+        float v[kColH + 10];
+#pragma unroll
+        for (int i = 0; i < kColH + 10; ++i) v[i] = hz[pl][rr0 + i][cc];
+#pragma unroll
+        for (int k = 0; k < kColH; ++k) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) t += win.g[i] * v[k + i];
+            acc[pl][k] = t;
+        }
+    }
     float s_ssim = 0.f, s_l1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < (kLT * kLT) / kLBlock; ++k) {
-        const int idx = threadIdx.x + k * kLBlock;
-        const int r = idx / kLT, c = idx % kLT;
-        const int y = y0 + r, x = x0 + c;
-        float mu1 = 0.f, mu2 = 0.f, eaa = 0.f, ebb = 0.f, eab = 0.f;
-#pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const float g = win.g[i];
-            mu1 += g * hz[0][r + i][c]; mu2 += g * hz[1][r + i][c];
-            eaa += g * hz[2][r + i][c]; ebb += g * hz[3][r + i][c]; eab += g * hz[4][r + i][c];
-        }
+    for (int k = 0; k < kColH; ++k) {
+        const int y = y0 + rr0 + k, x = x0 + cc;
+        const float mu1 = acc[0][k], mu2 = acc[1][k], eaa = acc[2][k], ebb = acc[3][k], eab = acc[4][k];
         if (y < H && x < W) {
             const float s1 = eaa - mu1 * mu1, s2 = ebb - mu2 * mu2, s12 = eab - mu1 * mu2;
             const float A1 = 2.f * mu1 * mu2 + kC1, A2 = 2.f * s12 + kC2;
             const float B1 = mu1 * mu1 + mu2 * mu2 + kC1, B2 = s1 + s2 + kC2;
             const float inv = 1.f / (B1 * B2);
-            const float m = A1 * A2 * inv;
-            s_ssim += m;
+            const float mm = A1 * A2 * inv;
+            s_ssim += mm;
             s_l1 += fabsf(ca[k] - cbv[k]);
             if (d_mu) {
                 const size_t p = plane + (size_t)y * W + x;
-                d_mu[p] = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * m * (B2 - B1) * inv;
-                d_eaa[p] = -m / B2;
+                d_mu[p] = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * mm * (B2 - B1) * inv;
+                d_eaa[p] = -mm / B2;
                 d_eab[p] = 2.f * A1 * inv;
             }
         }
@@ -161,9 +176,9 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, flo
                                                       const float *__restrict__ d_eaa, const float *__restrict__ d_eab,
                                                       float *__restrict__ grad_a)
 {
-    constexpr int kStageFloats = 3 * kLI * (kLI + 1);
-    __shared__ float lds[kStageFloats];                              // staged maps, then (over the same bytes) row-filtered maps
-    float (*sm)[kLI][kLI + 1] = reinterpret_cast<float (*)[kLI][kLI + 1]>(lds);
+    constexpr int kStageFloats = 3 * kLI * kLP;
+    __shared__ __attribute__((aligned(16))) float lds[kStageFloats];   // staged maps, then (over the same bytes) row-filtered maps
+    float (*sm)[kLI][kLP] = reinterpret_cast<float (*)[kLI][kLP]>(lds);
     float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
     const int ch = blockIdx.z, x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const size_t plane = (size_t)ch * H * W;
@@ -177,50 +192,58 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, flo
         sm[2][r][c] = in ? d_eab[p] : 0.f;
     }
     __syncthreads();
-    constexpr int kHzIters = (kLI * kLT + kLBlock - 1) / kLBlock;
-    float m0[kHzIters], m1[kHzIters], m2[kHzIters];
+    float m[3][kRowW];
+    const bool row_item = threadIdx.x < kRowItems;
+    const int hr = threadIdx.x / (kLT / kRowW), hc0 = (threadIdx.x % (kLT / kRowW)) * kRowW;
+    if (row_item) {
 #pragma unroll
-    for (int it = 0; it < kHzIters; ++it) {
-        const int idx = threadIdx.x + it * kLBlock;
-        m0[it] = m1[it] = m2[it] = 0.f;
-        if (idx < kLI * kLT) {
-            const int r = idx / kLT, c = idx % kLT;
+        for (int pl = 0; pl < 3; ++pl) {
+            float v[kRowW + 10];
 #pragma unroll
-            for (int i = 0; i < 11; ++i) {
-                const float g = win.g[i];
-                m0[it] += g * sm[0][r][c + i]; m1[it] += g * sm[1][r][c + i]; m2[it] += g * sm[2][r][c + i];
+            for (int i = 0; i < kRowW + 10; ++i) v[i] = sm[pl][hr][hc0 + i];
+#pragma unroll
+            for (int o = 0; o < kRowW; ++o) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 11; ++i) t += win.g[i] * v[o + i];
+                m[pl][o] = t;
             }
         }
     }
     __syncthreads();
+    if (row_item) {
 #pragma unroll
-    for (int it = 0; it < kHzIters; ++it) {
-        const int idx = threadIdx.x + it * kLBlock;
-        if (idx < kLI * kLT) {
-            const int r = idx / kLT, c = idx % kLT;
-            hz[0][r][c] = m0[it]; hz[1][r][c] = m1[it]; hz[2][r][c] = m2[it];
-        }
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int o = 0; o < kRowW; ++o) hz[pl][hr][hc0 + o] = m[pl][o];
     }
     __syncthreads();
     const float up = upstream ? upstream[0] : 1.f;
     const float k_ssim = -lambda * inv_count * up, k_l1 = (1.f - lambda) * inv_count * up;
+    const int cc = threadIdx.x % kLT, rr0 = (threadIdx.x / kLT) * kColH;
+    float acc[3][kColH];
 #pragma unroll
-    for (int k = 0; k < (kLT * kLT) / kLBlock; ++k) {
-        const int idx = threadIdx.x + k * kLBlock;
-        const int r = idx / kLT, c = idx % kLT;
-        const int y = y0 + r, x = x0 + c;
-        if (y >= H || x >= W) continue;
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int pl = 0; pl < 3; ++pl) {
+        float v[kColH + 10];
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const float g = win.g[i];
-            c0 += g * hz[0][r + i][c]; c1 += g * hz[1][r + i][c]; c2 += g * hz[2][r + i][c];
+        for (int i = 0; i < kColH + 10; ++i) v[i] = hz[pl][rr0 + i][cc];
+#pragma unroll
+        for (int k = 0; k < kColH; ++k) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) t += win.g[i] * v[k + i];
+            acc[pl][k] = t;
         }
+    }
+#pragma unroll
+    for (int k = 0; k < kColH; ++k) {
+        const int y = y0 + rr0 + k, x = x0 + cc;
+        if (y >= H || x >= W) continue;
         const size_t p = plane + (size_t)y * W + x;
         const float va = a[p], vb = b[p];
         const float d = va - vb;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        grad_a[p] = k_ssim * (c0 + 2.f * va * c1 + vb * c2) + k_l1 * sgn;
+        grad_a[p] = k_ssim * (acc[0][k] + 2.f * va * acc[1][k] + vb * acc[2][k]) + k_l1 * sgn;
     }
 }
 
