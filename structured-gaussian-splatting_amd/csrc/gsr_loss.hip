@@ -48,11 +48,57 @@ __device__ __forceinline__ float block_sum(float v, float *sh /*[4]*/)
 // Register-blocked separable window.  Row pass: 168 threads, each one row x 8 adjacent columns (18 staged values of a
 // and of b -> 8 x 5 moments); column pass: 256 threads, each one column x 4 adjacent rows (14 row-filtered values per
 // moment).  ~115 LDS reads per thread instead of ~350 for one-output-at-a-time.
-constexpr int kLP = kLI + 2;            // 44: staged row pitch (16-byte aligned rows)
+constexpr int kLX = 8;                  // staged columns start at x0 - 8 (16-byte aligned), the window needs x0 - 5
+constexpr int kLSW = kLT + 2 * kLX;     // 48 staged columns = 12 float4 per row
+constexpr int kLP = kLSW + 4;           // 52: staged row pitch (16-byte aligned, rows spread over 8 bank offsets)
+constexpr int kLO = kLX - kLH;          // 3: column of the staged row that holds x0 - 5
+
+// Stage rows y0-5 .. y0+36, columns x0-8 .. x0+39 of NP planes into LDS.  VEC (W % 4 == 0): one float4 per load, every
+// float4 is either fully inside or fully outside the image; all loads of a thread are issued before the first LDS write.
+template <int NP, bool VEC>
+__device__ __forceinline__ void stage_planes(const float *const (&src)[NP], float *lds /* [NP][kLI][kLP] */, size_t plane, int H, int W,
+                                             int x0, int y0)
+{
+    if constexpr (VEC) {
+        constexpr int kPerPlane = kLI * (kLSW / 4);                 // 504 float4
+        constexpr int kIters = (NP * kPerPlane + kLBlock - 1) / kLBlock;
+        float4 v[kIters];
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int idx = threadIdx.x + it * kLBlock;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NP * kPerPlane) {
+                const int pl = idx / kPerPlane, rem = idx % kPerPlane, r = rem / (kLSW / 4), c4 = rem % (kLSW / 4);
+                const int y = y0 - kLH + r, x = x0 - kLX + 4 * c4;
+                if (y >= 0 && y < H && x >= 0 && x < W)
+                    v[it] = *reinterpret_cast<const float4 *>(src[pl] + plane + (size_t)y * W + x);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) {
+            const int idx = threadIdx.x + it * kLBlock;
+            if (idx < NP * kPerPlane) {
+                const int pl = idx / kPerPlane, rem = idx % kPerPlane, r = rem / (kLSW / 4), c4 = rem % (kLSW / 4);
+                *reinterpret_cast<float4 *>(lds + ((size_t)pl * kLI + r) * kLP + 4 * c4) = v[it];
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < kLI * kLI; idx += kLBlock) {
+            const int r = idx / kLI, c = idx % kLI;
+            const int y = y0 - kLH + r, x = x0 - kLH + c;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            const size_t p = plane + (size_t)y * W + x;
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl) lds[((size_t)pl * kLI + r) * kLP + kLO + c] = in ? src[pl][p] : 0.f;
+        }
+    }
+}
+
 constexpr int kRowW = 8;                // outputs per thread in the row pass
 constexpr int kRowItems = kLI * (kLT / kRowW);     // 168
 constexpr int kColH = 4;                // outputs per thread in the column pass
 
+template <bool VEC>
 __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, const float *__restrict__ a, const float *__restrict__ b,
                                                       float *__restrict__ d_mu, float *__restrict__ d_eaa, float *__restrict__ d_eab,
                                                       float *__restrict__ partial_ssim, float *__restrict__ partial_l1)
@@ -68,12 +114,9 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
     float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
     const int ch = blockIdx.z, x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const size_t plane = (size_t)ch * H * W;
-    for (int idx = threadIdx.x; idx < kLI * kLI; idx += kLBlock) {
-        const int r = idx / kLI, c = idx % kLI;
-        const int y = y0 - kLH + r, x = x0 - kLH + c;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        sa[r][c] = in ? a[plane + (size_t)y * W + x] : 0.f;
-        sb[r][c] = in ? b[plane + (size_t)y * W + x] : 0.f;
+    {
+        const float *const src[2] = {a, b};
+        stage_planes<2, VEC>(src, lds, plane, H, W, x0, y0);
     }
     __syncthreads();
     // column-pass mapping of this thread: column cc, rows rr0 .. rr0 + 3; centre values for the L1 term are read now,
@@ -81,7 +124,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
     const int cc = threadIdx.x % kLT, rr0 = (threadIdx.x / kLT) * kColH;
     float ca[kColH], cbv[kColH];
 #pragma unroll
-    for (int k = 0; k < kColH; ++k) { ca[k] = sa[rr0 + k + kLH][cc + kLH]; cbv[k] = sb[rr0 + k + kLH][cc + kLH]; }
+    for (int k = 0; k < kColH; ++k) { ca[k] = sa[rr0 + k + kLH][kLO + cc + kLH]; cbv[k] = sb[rr0 + k + kLH][kLO + cc + kLH]; }
     // row pass
     float m[5][kRowW];
     const bool row_item = threadIdx.x < kRowItems;
@@ -89,7 +132,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
     if (row_item) {
         float va[kRowW + 10], vb[kRowW + 10];
 #pragma unroll
-        for (int i = 0; i < kRowW + 10; ++i) { va[i] = sa[hr][hc0 + i]; vb[i] = sb[hr][hc0 + i]; }
+        for (int i = 0; i < kRowW + 10; ++i) { va[i] = sa[hr][kLO + hc0 + i]; vb[i] = sb[hr][kLO + hc0 + i]; }
 #pragma unroll
         for (int o = 0; o < kRowW; ++o) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
@@ -170,6 +213,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_finish(int nblocks, float inv_
     }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, float inv_count, float lambda,
                                                       const float *__restrict__ upstream, const float *__restrict__ a,
                                                       const float *__restrict__ b, const float *__restrict__ d_mu,
@@ -182,14 +226,9 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, flo
     float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
     const int ch = blockIdx.z, x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
     const size_t plane = (size_t)ch * H * W;
-    for (int idx = threadIdx.x; idx < kLI * kLI; idx += kLBlock) {
-        const int r = idx / kLI, c = idx % kLI;
-        const int y = y0 - kLH + r, x = x0 - kLH + c;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        const size_t p = plane + (size_t)y * W + x;
-        sm[0][r][c] = in ? d_mu[p] : 0.f;
-        sm[1][r][c] = in ? d_eaa[p] : 0.f;
-        sm[2][r][c] = in ? d_eab[p] : 0.f;
+    {
+        const float *const src[3] = {d_mu, d_eaa, d_eab};
+        stage_planes<3, VEC>(src, lds, plane, H, W, x0, y0);
     }
     __syncthreads();
     float m[3][kRowW];
@@ -200,7 +239,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, flo
         for (int pl = 0; pl < 3; ++pl) {
             float v[kRowW + 10];
 #pragma unroll
-            for (int i = 0; i < kRowW + 10; ++i) v[i] = sm[pl][hr][hc0 + i];
+            for (int i = 0; i < kRowW + 10; ++i) v[i] = sm[pl][hr][kLO + hc0 + i];
 #pragma unroll
             for (int o = 0; o < kRowW; ++o) {
                 float t = 0.f;
@@ -290,7 +329,9 @@ int gsr_loss_l1_ssim_forward(int32_t channels, int32_t height, int32_t width, fl
     const Win win = make_window();
     {
         ProfileScope prof("loss_fwd", s);
-        hipLaunchKernelGGL(k_loss_fwd, grid, dim3(kLBlock), 0, s, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
+        const bool vec = width % 4 == 0 && ((uintptr_t)image % 16 == 0) && ((uintptr_t)target % 16 == 0);
+        if (vec) hipLaunchKernelGGL(k_loss_fwd<true>, grid, dim3(kLBlock), 0, s, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
+        else hipLaunchKernelGGL(k_loss_fwd<false>, grid, dim3(kLBlock), 0, s, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
         hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(kLBlock), 0, s, nblocks, inv_count, lambda_dssim, ps, pl, out3);
         GSR_LAUNCH_CHECK("loss_fwd", false, s);
     }
@@ -312,8 +353,14 @@ int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, f
     const Win win = make_window();
     {
         ProfileScope prof("loss_bwd", s);
-        hipLaunchKernelGGL(k_loss_bwd, grid, dim3(kLBlock), 0, s, height, width, win, inv_count, lambda_dssim, upstream, image,
-                           target, d_mu, d_eaa, d_eab, grad_image);
+        // the derivative maps are 256-byte aligned planes of the workspace: float4 rows whenever the width allows
+        const bool vec = width % 4 == 0 && ((uintptr_t)workspace % 16 == 0) && (((size_t)channels * height * width * 4) % 16 == 0);
+        if (vec)
+            hipLaunchKernelGGL(k_loss_bwd<true>, grid, dim3(kLBlock), 0, s, height, width, win, inv_count, lambda_dssim, upstream, image,
+                               target, d_mu, d_eaa, d_eab, grad_image);
+        else
+            hipLaunchKernelGGL(k_loss_bwd<false>, grid, dim3(kLBlock), 0, s, height, width, win, inv_count, lambda_dssim, upstream, image,
+                               target, d_mu, d_eaa, d_eab, grad_image);
         GSR_LAUNCH_CHECK("loss_bwd", false, s);
     }
     return GSR_OK;

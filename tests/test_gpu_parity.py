@@ -490,6 +490,17 @@ def test_fused_loss_matches_reference_golden():
     a2 = a.detach().clone().requires_grad_(True)
     (loss_utils.training_loss_torch(a2, b) * 3.0).backward()
     assert (a.grad - a2.grad).abs().max() <= 2e-4 * a2.grad.abs().max()
+    # widths that are / are not multiples of 4 (float4 and scalar staging), sizes that are not multiples of the tile
+    for (Hh, Ww) in ((70, 100), (67, 101), (33, 34), (5, 7)):
+        a = torch.rand(3, Hh, Ww, generator=gen).to(DEV).requires_grad_(True)
+        b = torch.rand(3, Hh, Ww, generator=gen).to(DEV)
+        la = loss_utils.training_loss(a, b)
+        la.backward()
+        a2 = a.detach().clone().requires_grad_(True)
+        lb = loss_utils.training_loss_torch(a2, b)
+        lb.backward()
+        assert abs(float(la.detach()) - float(lb.detach())) < 5e-6, (Hh, Ww)
+        assert (a.grad - a2.grad).abs().max() <= 2e-4 * a2.grad.abs().max(), (Hh, Ww)
 
 
 def test_cfg3_full_size_vs_oracle():
