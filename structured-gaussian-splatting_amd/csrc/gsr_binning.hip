@@ -44,7 +44,6 @@ GeomWS carve_geom(void *base, int P)
     for (int i = 0; i < 2; ++i) { w.sort_keys[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
     for (int i = 0; i < 2; ++i) { w.sort_vals[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
     w.order = w.sort_vals[0];                    // 4 passes of 8 bits: the result lands back in buffer 0
-    w.tiles_sorted = (uint32_t *)(b + o); o += align_up(Pn * 4);
     w.offs_full = (uint32_t *)(b + o); o += align_up(Pn * 4);
     w.cnt_open = (uint32_t *)(b + o); o += align_up(Pn * 4);
     w.offs_open = (uint32_t *)(b + o); o += align_up(Pn * 4);
@@ -89,18 +88,8 @@ BinningWS carve_binning(void *base, int64_t R)
 
 constexpr int kBinBlock = 256;
 
-// ---- depth order: sort (depth bits, Gaussian) pairs written by the preprocess kernel, then gather the
-// tile counts into depth order and scan them.
-__global__ __launch_bounds__(kBinBlock) void k_gather_tiles(int P, const uint32_t *__restrict__ order,
-                                                            const uint32_t *__restrict__ tiles, uint32_t *__restrict__ tiles_sorted,
-                                                            uint32_t *__restrict__ cnt_open)
-{
-    const int r = blockIdx.x * kBinBlock + threadIdx.x;
-    if (r >= P) return;
-    tiles_sorted[r] = tiles[order[r]];
-    cnt_open[r] = 0;
-}
-
+// ---- depth order: sort (depth bits, Gaussian) pairs written by the preprocess kernel, then scan the tile counts
+// in depth order (the scan gathers tiles[order[r]] itself).
 int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 {
     if (f.P == 0) return GSR_OK;
@@ -109,14 +98,8 @@ int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
                                           ws.radix_temp, &result, "depth_sort", debug, s)))
         return rc;
     if (result != 0) { set_error("internal: depth sort result buffer %d", result); return GSR_ERR_HIP; }
-    {
-        ProfileScope prof("gather_tiles", s);
-        hipLaunchKernelGGL(k_gather_tiles, dim3((f.P + kBinBlock - 1) / kBinBlock), dim3(kBinBlock), 0, s, f.P, ws.order,
-                           ws.tiles_touched, ws.tiles_sorted, ws.cnt_open);
-        GSR_LAUNCH_CHECK("gather_tiles", debug, s);
-    }
-    return launch_scan_inclusive(ws.tiles_sorted, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, nullptr, nullptr, "scan_tiles",
-                                 debug, s, &ws.ctrl->overflow);
+    return launch_scan_inclusive(ws.tiles_touched, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, nullptr, nullptr, "scan_tiles",
+                                 debug, s, &ws.ctrl->overflow, ws.order);
 }
 
 // ---- chunk plan (one block of 9 waves): wave 0 finds V (first rank whose key is 0xFFFFFFFF), wave 1+c the end

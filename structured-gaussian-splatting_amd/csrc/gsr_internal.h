@@ -82,8 +82,7 @@ struct GeomWS {                 // O(P): the reference's geomBuffer
     uint32_t *sort_keys[2];     // [P] x2 depth bits (0xFFFFFFFF = invisible)
     uint32_t *sort_vals[2];     // [P] x2 Gaussian index; after the sort: depth rank -> Gaussian
     uint32_t *order;            // alias of the sorted sort_vals buffer
-    uint32_t *tiles_sorted;     // [P]    tiles touched, in depth order
-    uint32_t *offs_full;        // [P]    inclusive scan of tiles_sorted
+    uint32_t *offs_full;        // [P]    inclusive scan of the tiles touched, in depth order
     uint32_t *cnt_open;         // [P]    by rank: instances emitted for this Gaussian
     uint32_t *offs_open;        // [P]    by rank: inclusive scan of cnt_open inside its chunk
     uint32_t *row_begin;        // [P]    by rank: absolute index of the Gaussian's first instance
@@ -120,7 +119,8 @@ BinningWS carve_binning(void *base, int64_t R);
 
 // ---- primitives (gsr_sort.hip)
 int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
-                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow = nullptr);
+                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow = nullptr,
+                          const uint32_t *gather = nullptr);
 template <typename K>
 int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
                       const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,

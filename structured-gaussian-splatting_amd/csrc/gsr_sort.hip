@@ -48,14 +48,15 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *sh_wav
     return inc + base;
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_scan_local(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                           uint32_t *__restrict__ block_sums, int n)
+// gather != nullptr: the scanned sequence is in[gather[i]] (tiles touched, read in depth order)
+__global__ __launch_bounds__(kScanBlock) void k_scan_local(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gather,
+                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, int n)
 {
     __shared__ uint32_t sh_wave[kScanBlock / kWave];
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     uint32_t v[kScanItems], sum = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; sum += v[i]; }
+    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? (gather ? in[gather[base + i]] : in[base + i]) : 0u; sum += v[i]; }
     uint32_t total;
     uint32_t run = block_incl_scan(sum, sh_wave, &total) - sum;
 #pragma unroll
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_add(uint32_t *__restrict__ 
 
 // short inputs (a chunk of a few thousand large splats): one block, one launch instead of three
 constexpr int kScanSmallMax = 8 * kScanTile;
-__global__ __launch_bounds__(kScanBlock) void k_scan_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int n,
+__global__ __launch_bounds__(kScanBlock) void k_scan_small(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gather,
+                                                           uint32_t *__restrict__ out, int n,
                                                            uint32_t *__restrict__ grand_total, const uint32_t *__restrict__ acc_in,
                                                            uint32_t *__restrict__ acc_out, uint32_t *__restrict__ overflow)
 {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_small(const uint32_t *__res
         const int base = t0 + threadIdx.x * kScanItems;
         uint32_t v[kScanItems], sum = 0;
 #pragma unroll
-        for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0u; sum += v[i]; }
+        for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? (gather ? in[gather[base + i]] : in[base + i]) : 0u; sum += v[i]; }
         uint32_t total;
         uint32_t run = carry + block_incl_scan(sum, sh_wave, &total) - sum;
 #pragma unroll
@@ -139,7 +141,7 @@ size_t scan_temp_bytes(int n) { return align_up((size_t)((n + kScanTile - 1) / k
 
 // out[i] = in[0] + ... + in[i]; optional *grand_total (device) = sum of all.
 int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
-                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow)
+                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow, const uint32_t *gather)
 {
     if (n <= 0) {
         if (overflow) GSR_HIP_CHECK(hipMemsetAsync(overflow, 0, 4, s));
@@ -149,13 +151,13 @@ int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, 
     }
     ProfileScope prof(name, s);
     if (n <= kScanSmallMax) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, s, in, out, n, grand_total, acc_in, acc_out, overflow);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, s, in, gather, out, n, grand_total, acc_in, acc_out, overflow);
         GSR_LAUNCH_CHECK(name, debug, s);
         return GSR_OK;
     }
     const int nb = (n + kScanTile - 1) / kScanTile;
     uint32_t *sums = (uint32_t *)temp;
-    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kScanBlock), 0, s, in, out, sums, n);
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kScanBlock), 0, s, in, gather, out, sums, n);
     hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(kScanBlock), 0, s, sums, nb, grand_total, acc_in, acc_out, overflow);
     if (nb > 1) hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanBlock), 0, s, out, sums, n);
     GSR_LAUNCH_CHECK(name, debug, s);
