@@ -114,11 +114,14 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
     geom_bytes, image_bytes = N.workspace_sizes(fr.desc)
     fr.geom_ws = _workspace(geom_bytes, device)
     fr.image_ws = _workspace(image_bytes, device)
-    fr.radii = torch.zeros(P, dtype=torch.int32, device=device)
+    fr.radii = torch.empty(P, dtype=torch.int32, device=device)            # every entry is written by the preprocess kernel
     with torch.cuda.device(device):
         fr.plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device)
         fr.binning_ws = _workspace(N.binning_size(fr.desc, fr.R), device)
-        color = out_color if out_color is not None else torch.zeros(3, H, W, dtype=torch.float32, device=device)
+        if out_color is not None:
+            color = out_color
+        else:       # a full-frame render writes every pixel; a slab leaves the other rows untouched, so those start at 0
+            color = (torch.empty if tile_rows is None else torch.zeros)(3, H, W, dtype=torch.float32, device=device)
         N.forward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, color, device)
     return color, fr.radii, fr
 
