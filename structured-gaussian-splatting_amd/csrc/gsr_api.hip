@@ -167,13 +167,18 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     plan->num_chunks = 1;
     if (f.P == 0) return GSR_OK;
     GeomWS gw = carve_geom(geom_ws, f.P);
-    if ((rc = launch_preprocess(f, *cam, *g, gw, radii, dbg, s))) return rc;
+    if ((rc = launch_preprocess(f, *cam, *g, gw, radii, desc->prefiltered != 0, dbg, s))) return rc;
     if ((rc = launch_depth_order(f, gw, dbg, s))) return rc;
     if ((rc = launch_chunk_plan(f, gw, dbg, s))) return rc;
     // The one host synchronisation of this stage: the plan (R sizes the binning workspace).
     Ctrl h;
     GSR_HIP_CHECK(hipMemcpyAsync(&h, gw.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
     GSR_HIP_CHECK(hipStreamSynchronize(s));
+    if (desc->prefiltered && h.prefilter_violation) {
+        set_error("prefiltered is set but at least one Gaussian fails the frustum test (view depth <= 0.2): the caller's "
+                  "pre-filter and the rasterizer disagree");
+        return GSR_ERR_PREFILTERED;
+    }
     if (h.overflow) {
         set_error("the frame's tile instances (sum of tiles touched over %d visible Gaussians) exceed 2^32 - 1: "
                   "split the frame into tile-row slabs (gsr_frame_desc.tile_row_begin/end)", (int)h.V);

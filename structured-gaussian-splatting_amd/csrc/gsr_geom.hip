@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
                                                            const float *__restrict__ colpre, float4 *__restrict__ records,
                                                            uint32_t *__restrict__ tiles, uint8_t *__restrict__ clamped,
                                                            int32_t *__restrict__ radii, uint32_t *__restrict__ sort_keys,
-                                                           uint32_t *__restrict__ sort_vals)
+                                                           uint32_t *__restrict__ sort_vals, uint32_t *__restrict__ prefilter_flag)
 {
     const int i = blockIdx.x * kGeomBlock + threadIdx.x;
     if (i >= f.P) return;
@@ -88,7 +88,11 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
     cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
     GaussIn<DEG, RAW> in;
     const float p0[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
-    load_gaussian<DEG, RAW>(i, f.M, means, scales, rots, covpre, opac, shs, shs_rest, in_frustum(p0, V), in);
+    const bool near_ok = in_frustum(p0, V);
+    // prefiltered = "the caller guarantees every point passes the frustum test" (the upstream kernel traps when one
+    // does not); here the frame is refused with GSR_ERR_PREFILTERED after the plan readback
+    if (prefilter_flag && !near_ok) *prefilter_flag = 1u;
+    load_gaussian<DEG, RAW>(i, f.M, means, scales, rots, covpre, opac, shs, shs_rest, near_ok, in);
     PreOut o;
     preprocess_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.opacity, in.sh(),
                         (!RAW && colpre) ? colpre + 3 * (size_t)i : nullptr, o);
@@ -106,16 +110,21 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
 }
 
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
-                      bool debug, hipStream_t s)
+                      bool prefiltered, bool debug, hipStream_t s)
 {
     if (f.P == 0) return GSR_OK;
     const int grid = (f.P + kGeomBlock - 1) / kGeomBlock;
+    uint32_t *prefilter_flag = nullptr;
+    if (prefiltered) {
+        prefilter_flag = &ws.ctrl->prefilter_violation;
+        GSR_HIP_CHECK(hipMemsetAsync(prefilter_flag, 0, 4, s));
+    }
     ProfileScope prof("preprocess", s);
 #define GSR_PRE(DEG, RAW)                                                                                           \
     hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
                        cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs, g.shs_rest,   \
                        g.colors_precomp, ws.records, ws.tiles_touched, ws.clamped, radii, ws.sort_keys[0],              \
-                       ws.sort_vals[0])
+                       ws.sort_vals[0], prefilter_flag)
     if (g.raw) {
         switch (f.D) {
             case 0: GSR_PRE(0, true); break;

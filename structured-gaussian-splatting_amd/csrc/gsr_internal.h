@@ -74,6 +74,7 @@ struct Ctrl {                   // small device-side control block of one frame
     uint32_t chunk_R[GSR_MAX_CHUNKS];          // instances actually emitted
     uint32_t chunk_base[GSR_MAX_CHUNKS + 1];   // first absolute instance index of the chunk
     uint32_t overflow;                         // 1 = the sum of tiles touched does not fit 32 bits
+    uint32_t prefilter_violation;              // 1 = prefiltered was set and a Gaussian failed the frustum test (A.1)
 };
 struct GeomWS {                 // O(P): the reference's geomBuffer
     float4 *records;            // [P,3]  Splat records, by Gaussian
@@ -128,7 +129,7 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
 
 // ---- kernel launchers (each returns a gsr_status)
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
-                      bool debug, hipStream_t s);
+                      bool prefiltered, bool debug, hipStream_t s);
 int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
 int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);

@@ -776,3 +776,22 @@ def test_chunks_of_few_large_splats(scale_lo, scale_hi, label):
     color, radii, grads = _run_gpu(kw, gimg)
     _check_forward(kw, fr64, color, radii)
     _check_grads(fr64, fr64.backward(gimg), grads, ["means3D", "means2D", "opacities", "shs", "scales", "rotations"])
+
+
+def test_prefiltered_flag():
+    """`prefiltered=True` promises that every Gaussian passes the frustum test (A.1).  With the promise kept the frame
+    is the same as without the flag; with it broken the upstream kernel traps, here the call fails with
+    GSR_ERR_PREFILTERED and a message."""
+    from diff_gaussian_rasterization import GaussianRasterizer, _native
+    kw = _fixture_kwargs(dict(P=500, W=96, H=64, D=1, seed=9))
+    kw["means3D"] = kw["means3D"].copy()
+    kw["means3D"][:, 2] = np.abs(kw["means3D"][:, 2]) + 0.5           # all in front of the near cut
+    rs, inp = _settings(kw), _inputs(kw, False)
+    z = torch.zeros(500, 3, device=DEV)
+    ref, _ = GaussianRasterizer(rs)(means2D=z, **inp)
+    got, _ = GaussianRasterizer(rs._replace(prefiltered=True))(means2D=z, **inp)
+    assert torch.equal(ref, got)
+    inp["means3D"][7, 2] = 0.1                                           # behind the 0.2 cut
+    with pytest.raises(_native.GsrError, match="prefiltered"):
+        GaussianRasterizer(rs._replace(prefiltered=True))(means2D=z, **inp)
+    GaussianRasterizer(rs)(means2D=z, **inp)                             # without the promise: culled silently
