@@ -39,7 +39,7 @@ def algorithmic_bytes(P, V, Re, N, Tn, K, M, Vlive, C=3):
     return {
         "preprocess": 52 * P + (12 * K + 67) * V,          # K1 (+ 8 B/Gaussian depth-sort key/value)
         "depth_sort": 16 * P,                               # minimum: one read + one write of (key, value)
-        "gather_tiles": 12 * P, "scan_tiles": 8 * P, "chunk_plan": 0, "open_sat": 8 * Tn,
+        "scan_tiles": 12 * P, "chunk_plan": 0, "open_count": 8 * Tn,    # the scan gathers tiles[order[r]] itself
         "count_open": 56 * V, "scan_open": 8 * V,
         "emit": 12 * Re,                                    # K3: key 4 + slot 4 + Gaussian 4 per instance
         "tile_sort": 16 * Re,                               # K4 minimum: one read + one write of (tile, slot)
