@@ -171,6 +171,9 @@ def main():
         per_step_ms = ms / args.steps
         per_kernel[k] = dict(ms_per_step=per_step_ms, launches_per_step=n / args.steps,
                              alg_GBs=(alg.get(k, 0) / 1e9) / (per_step_ms / 1e3) if per_step_ms > 0 else None)
+        keys = {"depth_sort": P, "tile_sort": Re}.get(k)             # SURVEY 8d secondary rate for K4: keys/s
+        if keys is not None and per_step_ms > 0:
+            per_kernel[k]["Gkeys_per_s"] = keys / 1e9 / (per_step_ms / 1e3)
     raster_ms = sum(ms for ms, _ in prof.values()) / args.steps
     dom = max(prof, key=lambda k: prof[k][0])
     launches = max(prof[dom][1], 1)
@@ -346,9 +349,18 @@ def _cpu_baseline(scene, cam, cfg):
     fr = oracle.rasterize(dtype=np.float32, parallel=True, **kw)
     fr.backward(g, parallel=True)
     dt = time.perf_counter() - t0
+    # SURVEY 8d also asks for the reference-semantics Python SH path (the `convert_SHs_python` twin, utils/sh_utils.py
+    # eval_sh + clamp) on the host cores for the same P: this repo's torch mirror of it, forward only
+    from gaussian_renderer import eval_sh
+    sh_view = a["shs"].transpose(1, 2).contiguous()
+    dirs = torch.nn.functional.normalize(a["means3D"] - cam.camera_center[None, :], dim=1)
+    t1 = time.perf_counter()
+    torch.clamp_min(eval_sh(cfg["D"], sh_view, dirs) + 0.5, 0.0)
+    sh_ms = 1e3 * (time.perf_counter() - t1)
     return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"1 frame of the same workload, rasterizer forward+backward only (no loss), C oracle with "
-                      f"OpenMP over {cores} host threads (sort and per-Gaussian stages serial); {dt:.1f} s"}
+                      f"OpenMP over {cores} host threads (sort and per-Gaussian stages serial); {dt:.1f} s",
+            "python_sh_path_ms": round(sh_ms, 1), "torch_threads": torch.get_num_threads()}
 
 
 if __name__ == "__main__":
