@@ -208,11 +208,10 @@ class _ShardedRasterize(torch.autograd.Function):
             if order is None or n_max >= P:
                 screen = comm.all_reduce_sum(partial.contiguous())
             else:
-                screen = partial
+                screen = partial                                    # rows outside the prefix are zero on every rank
                 if n_max > 0:
                     idx = order[:n_max].long()
-                    screen = partial.clone()
-                    screen[idx] = comm.all_reduce_sum(partial[idx].contiguous())
+                    screen[idx] = comm.all_reduce_sum(partial[idx].contiguous())       # in place: `partial` is not used again
             # (3) every rank runs the whole geometry backward: full parameter gradients, no further collective
             out = list(backend.backward_geom(frame, screen, needs, 0, P, n_max if order is not None else -1))
         else:
