@@ -309,6 +309,31 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
     }
 }
 
+// ---- one launch that zero-fills up to nine output tensors (the sparse path's "memset"): the segments are laid end to
+// end in a virtual float index space; each thread clears a float4 where the 16 bytes lie inside one segment.
+struct ZeroSegs {
+    float *ptr[9];
+    size_t len[9];      // floats to clear in segment i
+    size_t end[9];      // exclusive end of segment i in the virtual index space (lengths rounded up to 4 floats)
+    int n;
+};
+
+__global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z)
+{
+    const size_t total = z.end[z.n - 1];
+    const size_t stride = (size_t)gridDim.x * kGeomBlock * 4;
+    for (size_t v = ((size_t)blockIdx.x * kGeomBlock + threadIdx.x) * 4; v < total; v += stride) {
+        int sgm = 0;
+        while (v >= z.end[sgm]) ++sgm;
+        const size_t off = v - (sgm ? z.end[sgm - 1] : 0);           // multiple of 4 inside the segment
+        float *p = z.ptr[sgm] + off;
+        if (off + 4 <= z.len[sgm] && (((uintptr_t)p) & 15) == 0) *reinterpret_cast<float4 *>(p) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else
+            for (int e = 0; e < 4; ++e)
+                if (off + e < z.len[sgm]) p[e] = 0.f;
+    }
+}
+
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
                     const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s)
 {
@@ -317,15 +342,25 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
         // depth-complex frame: almost every gradient row is zero -> memset the outputs, then visit the binned prefix only
         ProfileScope prof("geom_bwd", s);
         const size_t P = (size_t)f.P;
-        if (out.means3D) GSR_HIP_CHECK(hipMemsetAsync(out.means3D, 0, P * 12, s));
-        if (out.means2D) GSR_HIP_CHECK(hipMemsetAsync(out.means2D, 0, P * 12, s));
-        if (out.opacities) GSR_HIP_CHECK(hipMemsetAsync(out.opacities, 0, P * 4, s));
-        if (out.colors_precomp && g.colors_precomp) GSR_HIP_CHECK(hipMemsetAsync(out.colors_precomp, 0, P * 12, s));
-        if (out.scales && !g.cov3D_precomp) GSR_HIP_CHECK(hipMemsetAsync(out.scales, 0, P * 12, s));
-        if (out.rotations && !g.cov3D_precomp) GSR_HIP_CHECK(hipMemsetAsync(out.rotations, 0, P * 16, s));
-        if (out.cov3D_precomp && g.cov3D_precomp) GSR_HIP_CHECK(hipMemsetAsync(out.cov3D_precomp, 0, P * 24, s));
-        if (out.shs && g.shs) GSR_HIP_CHECK(hipMemsetAsync(out.shs, 0, P * 12 * (size_t)(g.raw ? 1 : f.M), s));
-        if (g.raw && out.shs_rest && f.M > 1) GSR_HIP_CHECK(hipMemsetAsync(out.shs_rest, 0, P * 12 * (size_t)(f.M - 1), s));
+        ZeroSegs z;
+        z.n = 0;
+        auto add = [&](float *ptr, size_t floats) {
+            if (ptr && floats) { z.ptr[z.n] = ptr; z.len[z.n] = floats; z.end[z.n] = (z.n ? z.end[z.n - 1] : 0) + ((floats + 3) & ~(size_t)3); ++z.n; }
+        };
+        add(out.means3D, P * 3);
+        add(out.means2D, P * 3);
+        add(out.opacities, P);
+        if (g.colors_precomp) add(out.colors_precomp, P * 3);
+        if (!g.cov3D_precomp) { add(out.scales, P * 3); add(out.rotations, P * 4); }
+        if (g.cov3D_precomp) add(out.cov3D_precomp, P * 6);
+        if (g.shs) add(out.shs, P * 3 * (size_t)(g.raw ? 1 : f.M));
+        if (g.raw && f.M > 1) add(out.shs_rest, P * 3 * (size_t)(f.M - 1));
+        if (z.n > 0) {
+            const size_t total = z.end[z.n - 1];
+            size_t blocks = (total / 4 + kGeomBlock - 1) / kGeomBlock / 4 + 1;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(k_zero_segments, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z);
+        }
         if (n_ranks > 0) {
             const int sgrid = (n_ranks + kGeomBlock - 1) / kGeomBlock;
 #define GSR_GS(DEG, RAW)                                                                                                     \
