@@ -22,7 +22,7 @@ from collections import defaultdict
 NAMES = {
     "gsr::k_render_bwd": "render_bwd", "gsr::k_render_fwd": "render_fwd", "void gsr::k_geom_bwd<": "geom_bwd",
     "void gsr::k_geom_bwd_sparse<": "geom_bwd", "void gsr::k_preprocess<": "preprocess",
-    "void gsr::k_reduce_rows<": "reduce_rows", "gsr::k_loss_fwd": "loss_fwd", "gsr::k_loss_bwd": "loss_bwd",
+    "void gsr::k_reduce_rows<": "reduce_rows", "void gsr::k_loss_fwd<": "loss_fwd", "void gsr::k_loss_bwd<": "loss_bwd",
     "void gsr::k_emit_team<": "emit", "void gsr::k_count_team<": "count_open", "void gsr::k_bin_chunk<false>": "count_open",
     "void gsr::k_bin_chunk<true>": "emit", "gsr::k_ranges": "ranges",
 }
