@@ -24,6 +24,25 @@ constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 struct Win { float g[11]; };
 
+// 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so XCD x gets the contiguous run of
+// (channel, tile row, tile column) items [start(x), start(x) + count(x)): neighbouring tiles, whose 5-px halos
+// overlap, then share one L2 instead of fetching the halo from HBM once per XCD.
+struct LossTile { int ch, x0, y0, bid; };
+__device__ __forceinline__ LossTile loss_tile(int tiles_x, int tiles_y, int channels)
+{
+    const int n = tiles_x * tiles_y * channels;
+    const int b = (int)blockIdx.x;
+    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+    const int t = x * q + (x < r ? x : r) + i;
+    LossTile o;
+    o.bid = t;
+    o.ch = t / (tiles_x * tiles_y);
+    const int rem = t - o.ch * tiles_x * tiles_y;
+    o.y0 = (rem / tiles_x) * kLT;
+    o.x0 = (rem % tiles_x) * kLT;
+    return o;
+}
+
 static Win make_window()
 {
     // exactly utils/loss_utils.py:20-22: exp(-(x - 5)^2 / (2 * 1.5^2)) in fp32, normalised by its fp32 sum
@@ -99,7 +118,7 @@ constexpr int kRowItems = kLI * (kLT / kRowW);     // 168
 constexpr int kColH = 4;                // outputs per thread in the column pass
 
 template <bool VEC>
-__global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, const float *__restrict__ a, const float *__restrict__ b,
+__global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, Win win, const float *__restrict__ a, const float *__restrict__ b,
                                                       float *__restrict__ d_mu, float *__restrict__ d_eaa, float *__restrict__ d_eab,
                                                       float *__restrict__ partial_ssim, float *__restrict__ partial_l1)
 {
@@ -112,7 +131,8 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
     float (*sa)[kLP] = reinterpret_cast<float (*)[kLP]>(lds);
     float (*sb)[kLP] = reinterpret_cast<float (*)[kLP]>(lds + kLI * kLP);
     float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
-    const int ch = blockIdx.z, x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const LossTile lt = loss_tile((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
     const size_t plane = (size_t)ch * H * W;
     {
         const float *const src[2] = {a, b};
@@ -192,9 +212,8 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int H, int W, Win win, con
     const float t_ssim = block_sum(s_ssim, red);
     const float t_l1 = block_sum(s_l1, red);
     if (threadIdx.x == 0) {
-        const int bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        partial_ssim[bid] = t_ssim;
-        partial_l1[bid] = t_l1;
+        partial_ssim[lt.bid] = t_ssim;
+        partial_l1[lt.bid] = t_l1;
     }
 }
 
@@ -214,7 +233,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_finish(int nblocks, float inv_
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, float inv_count, float lambda,
+__global__ __launch_bounds__(kLBlock) void k_loss_bwd(int C, int H, int W, Win win, float inv_count, float lambda,
                                                       const float *__restrict__ upstream, const float *__restrict__ a,
                                                       const float *__restrict__ b, const float *__restrict__ d_mu,
                                                       const float *__restrict__ d_eaa, const float *__restrict__ d_eab,
@@ -224,7 +243,8 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int H, int W, Win win, flo
     __shared__ __attribute__((aligned(16))) float lds[kStageFloats];   // staged maps, then (over the same bytes) row-filtered maps
     float (*sm)[kLI][kLP] = reinterpret_cast<float (*)[kLI][kLP]>(lds);
     float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
-    const int ch = blockIdx.z, x0 = blockIdx.x * kLT, y0 = blockIdx.y * kLT;
+    const LossTile lt = loss_tile((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
     const size_t plane = (size_t)ch * H * W;
     {
         const float *const src[3] = {d_mu, d_eaa, d_eab};
@@ -323,15 +343,15 @@ int gsr_loss_l1_ssim_forward(int32_t channels, int32_t height, int32_t width, fl
     hipStream_t s = (hipStream_t)stream;
     float *d_mu, *d_eaa, *d_eab, *ps, *pl;
     carve_loss(workspace, channels, height, width, &d_mu, &d_eaa, &d_eab, &ps, &pl);
-    const dim3 grid((width + kLT - 1) / kLT, (height + kLT - 1) / kLT, channels);
-    const int nblocks = (int)(grid.x * grid.y * grid.z);
+    const int nblocks = ((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT) * channels;
+    const dim3 grid(nblocks);
     const float inv_count = 1.f / ((float)channels * (float)height * (float)width);
     const Win win = make_window();
     {
         ProfileScope prof("loss_fwd", s);
         const bool vec = width % 4 == 0 && ((uintptr_t)image % 16 == 0) && ((uintptr_t)target % 16 == 0);
-        if (vec) hipLaunchKernelGGL(k_loss_fwd<true>, grid, dim3(kLBlock), 0, s, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
-        else hipLaunchKernelGGL(k_loss_fwd<false>, grid, dim3(kLBlock), 0, s, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
+        if (vec) hipLaunchKernelGGL(k_loss_fwd<true>, grid, dim3(kLBlock), 0, s, channels, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
+        else hipLaunchKernelGGL(k_loss_fwd<false>, grid, dim3(kLBlock), 0, s, channels, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
         hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(kLBlock), 0, s, nblocks, inv_count, lambda_dssim, ps, pl, out3);
         GSR_LAUNCH_CHECK("loss_fwd", false, s);
     }
@@ -348,7 +368,7 @@ int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, f
     hipStream_t s = (hipStream_t)stream;
     float *d_mu, *d_eaa, *d_eab, *ps, *pl;
     carve_loss(const_cast<void *>(workspace), channels, height, width, &d_mu, &d_eaa, &d_eab, &ps, &pl);
-    const dim3 grid((width + kLT - 1) / kLT, (height + kLT - 1) / kLT, channels);
+    const dim3 grid(((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT) * channels);
     const float inv_count = 1.f / ((float)channels * (float)height * (float)width);
     const Win win = make_window();
     {
@@ -356,10 +376,10 @@ int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, f
         // the derivative maps are 256-byte aligned planes of the workspace: float4 rows whenever the width allows
         const bool vec = width % 4 == 0 && ((uintptr_t)workspace % 16 == 0) && (((size_t)channels * height * width * 4) % 16 == 0);
         if (vec)
-            hipLaunchKernelGGL(k_loss_bwd<true>, grid, dim3(kLBlock), 0, s, height, width, win, inv_count, lambda_dssim, upstream, image,
+            hipLaunchKernelGGL(k_loss_bwd<true>, grid, dim3(kLBlock), 0, s, channels, height, width, win, inv_count, lambda_dssim, upstream, image,
                                target, d_mu, d_eaa, d_eab, grad_image);
         else
-            hipLaunchKernelGGL(k_loss_bwd<false>, grid, dim3(kLBlock), 0, s, height, width, win, inv_count, lambda_dssim, upstream, image,
+            hipLaunchKernelGGL(k_loss_bwd<false>, grid, dim3(kLBlock), 0, s, channels, height, width, win, inv_count, lambda_dssim, upstream, image,
                                target, d_mu, d_eaa, d_eab, grad_image);
         GSR_LAUNCH_CHECK("loss_bwd", false, s);
     }
