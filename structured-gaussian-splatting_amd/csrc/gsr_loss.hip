@@ -23,6 +23,7 @@ constexpr int kLBlock = 256;
 constexpr float kC1 = 0.01f * 0.01f, kC2 = 0.03f * 0.03f;
 
 struct Win { float g[11]; };
+typedef float v2f __attribute__((ext_vector_type(2)));     // packed-fp32 operand: two moments of one pixel per VALU issue
 
 // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so XCD x gets the contiguous run of
 // (channel, tile row, tile column) items [start(x), start(x) + count(x)): neighbouring tiles, whose 5-px halos
@@ -150,19 +151,22 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, Win w
     const bool row_item = threadIdx.x < kRowItems;
     const int hr = threadIdx.x / (kLT / kRowW), hc0 = (threadIdx.x % (kLT / kRowW)) * kRowW;
     if (row_item) {
-        float va[kRowW + 10], vb[kRowW + 10];
-#pragma unroll
-        for (int i = 0; i < kRowW + 10; ++i) { va[i] = sa[hr][kLO + hc0 + i]; vb[i] = sb[hr][kLO + hc0 + i]; }
+        v2f ab[kRowW + 10];                                   // (a, b) of one staged pixel: the moments pair up as
+#pragma unroll                                                 // (E[a], E[b]) and (E[a^2], E[b^2]) -> v_pk_fma_f32
+        for (int i = 0; i < kRowW + 10; ++i) ab[i] = v2f{sa[hr][kLO + hc0 + i], sb[hr][kLO + hc0 + i]};
 #pragma unroll
         for (int o = 0; o < kRowW; ++o) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+            v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
+            float s4 = 0.f;
 #pragma unroll
             for (int i = 0; i < 11; ++i) {
-                const float g = win.g[i], x = va[o + i], y = vb[o + i];
-                const float gx = g * x, gy = g * y;
-                s0 += gx; s1 += gy; s2 += gx * x; s3 += gy * y; s4 += gx * y;
+                const v2f xy = ab[o + i];
+                const v2f gxy = win.g[i] * xy;
+                s01 += gxy;
+                s23 += gxy * xy;
+                s4 += gxy[0] * xy[1];
             }
-            m[0][o] = s0; m[1][o] = s1; m[2][o] = s2; m[3][o] = s3; m[4][o] = s4;
+            m[0][o] = s01[0]; m[1][o] = s01[1]; m[2][o] = s23[0]; m[3][o] = s23[1]; m[4][o] = s4;
         }
     }
     __syncthreads();
@@ -173,19 +177,24 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, Win w
             for (int o = 0; o < kRowW; ++o) hz[pl][hr][hc0 + o] = m[pl][o];
     }
     __syncthreads();
-    // column pass
+    // column pass, moments in pairs again
     float acc[5][kColH];
+    {
+        v2f v01[kColH + 10], v23[kColH + 10];
+        float v4[kColH + 10];
 #pragma unroll
-    for (int pl = 0; pl < 5; ++pl) {
-        float v[kColH + 10];
-#pragma unroll
-        for (int i = 0; i < kColH + 10; ++i) v[i] = hz[pl][rr0 + i][cc];
+        for (int i = 0; i < kColH + 10; ++i) {
+            v01[i] = v2f{hz[0][rr0 + i][cc], hz[1][rr0 + i][cc]};
+            v23[i] = v2f{hz[2][rr0 + i][cc], hz[3][rr0 + i][cc]};
+            v4[i] = hz[4][rr0 + i][cc];
+        }
 #pragma unroll
         for (int k = 0; k < kColH; ++k) {
-            float t = 0.f;
+            v2f t01 = {0.f, 0.f}, t23 = {0.f, 0.f};
+            float t4 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 11; ++i) t += win.g[i] * v[k + i];
-            acc[pl][k] = t;
+            for (int i = 0; i < 11; ++i) { const float g = win.g[i]; t01 += g * v01[k + i]; t23 += g * v23[k + i]; t4 += g * v4[k + i]; }
+            acc[0][k] = t01[0]; acc[1][k] = t01[1]; acc[2][k] = t23[0]; acc[3][k] = t23[1]; acc[4][k] = t4;
         }
     }
     float s_ssim = 0.f, s_l1 = 0.f;
@@ -222,7 +231,17 @@ __global__ __launch_bounds__(kLBlock) void k_loss_finish(int nblocks, float inv_
 {
     __shared__ float red[4];
     float s = 0.f, l = 0.f;
-    for (int i = threadIdx.x; i < nblocks; i += kLBlock) { s += partial_ssim[i]; l += partial_l1[i]; }
+    for (int i0 = threadIdx.x; i0 < nblocks; i0 += 8 * kLBlock) {        // eight independent loads in flight per thread
+        float ps[8], pl[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * kLBlock;
+            ps[u] = i < nblocks ? partial_ssim[i] : 0.f;
+            pl[u] = i < nblocks ? partial_l1[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += ps[u]; l += pl[u]; }                // fixed order: deterministic
+    }
     const float ts = block_sum(s, red) * inv_count;
     const float tl = block_sum(l, red) * inv_count;
     if (threadIdx.x == 0) {
