@@ -63,6 +63,9 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(-(-n // step) * step, dtype=torch.uint8, device=device)
 
 
+_binning_guess = {}        # (P, W, H, slab, device) -> bytes of the last binning workspace of that frame shape
+
+
 class _Frame:
     """Native handles of one forward pass, kept alive by autograd's ctx for the backward."""
     __slots__ = ("desc", "cam", "keep", "plan", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device", "raw")
@@ -116,12 +119,24 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
     fr.image_ws = _workspace(image_bytes, device)
     fr.radii = torch.empty(P, dtype=torch.int32, device=device)            # every entry is written by the preprocess kernel
     with torch.cuda.device(device):
-        fr.plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device)
-        fr.binning_ws = _workspace(N.binning_size(fr.desc, fr.R), device)
+        # Everything that can be allocated before the plan readback is: the stream is idle while the host waits for R,
+        # so the first kernels of the second stage should follow the readback as closely as possible.  The binning
+        # workspace is guessed from the last frame of the same shape and re-allocated only when R outgrew it.
         if out_color is not None:
             color = out_color
         else:       # a full-frame render writes every pixel; a slab leaves the other rows untouched, so those start at 0
             color = (torch.empty if tile_rows is None else torch.zeros)(3, H, W, dtype=torch.float32, device=device)
+        guess_key = (P, W, H, None if tile_rows is None else tuple(int(v) for v in tile_rows), device.index)
+        guess = _binning_guess.get(guess_key, 0)
+        binning = _workspace(guess, device) if guess > 0 else None
+        fr.plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device)
+        need = N.binning_size(fr.desc, fr.R)
+        if binning is None or binning.numel() < need:
+            binning = _workspace(need, device)
+        _binning_guess[guess_key] = need
+        if len(_binning_guess) > 64:
+            _binning_guess.pop(next(iter(_binning_guess)))
+        fr.binning_ws = binning
         N.forward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, color, device)
     return color, fr.radii, fr
 
