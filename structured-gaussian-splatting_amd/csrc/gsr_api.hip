@@ -124,6 +124,33 @@ static int validate_inputs(const gsr_frame_desc *d, const gsr_camera *c, const g
     return GSR_OK;
 }
 
+// Control-block readback: the two host decisions of a frame (R / chunk plan, open-tile count) wait for 160 bytes.
+// The copy lands in pinned memory and the host POLLS an event instead of sleeping in hipStreamSynchronize: the
+// blocking wait's wake-up costs tens of microseconds of idle stream per readback at a 1.5 ms step.
+struct Readback {            // one per host thread, never freed (160 pinned bytes + an event; the HIP runtime may already be
+    Ctrl *pinned = nullptr;  // gone when thread-local destructors run)
+    hipEvent_t ev = nullptr;
+};
+static thread_local Readback tl_readback;
+
+static int read_ctrl(const Ctrl *dev, Ctrl *out, hipStream_t s)
+{
+    Readback &rb = tl_readback;
+    if (!rb.pinned) {
+        GSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&rb.pinned), sizeof(Ctrl), hipHostMallocDefault));
+        GSR_HIP_CHECK(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
+    }
+    GSR_HIP_CHECK(hipMemcpyAsync(rb.pinned, dev, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+    GSR_HIP_CHECK(hipEventRecord(rb.ev, s));
+    for (;;) {
+        const hipError_t e = hipEventQuery(rb.ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) { set_error("control-block readback: %s", hipGetErrorString(e)); return GSR_ERR_HIP; }
+    }
+    *out = *rb.pinned;
+    return GSR_OK;
+}
+
 }  // namespace gsr
 
 using namespace gsr;
@@ -172,8 +199,7 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     if ((rc = launch_chunk_plan(f, gw, dbg, s))) return rc;
     // The one host synchronisation of this stage: the plan (R sizes the binning workspace).
     Ctrl h;
-    GSR_HIP_CHECK(hipMemcpyAsync(&h, gw.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
-    GSR_HIP_CHECK(hipStreamSynchronize(s));
+    if ((rc = read_ctrl(gw.ctrl, &h, s))) return rc;
     if (desc->prefiltered && h.prefilter_violation) {
         set_error("prefiltered is set but at least one Gaussian fails the frustum test (view depth <= 0.2): the caller's "
                   "pre-filter and the rasterizer disagree");
@@ -240,8 +266,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *
         if (last) break;
         if ((rc = launch_open_update(f, gw, iw, dbg, s))) return rc;
         Ctrl h;
-        GSR_HIP_CHECK(hipMemcpyAsync(&h, gw.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
-        GSR_HIP_CHECK(hipStreamSynchronize(s));
+        if ((rc = read_ctrl(gw.ctrl, &h, s))) return rc;
         plan->instances_emitted = (int64_t)h.chunk_base[c + 1];
         if (h.open_count == 0) break;
     }
