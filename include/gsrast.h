@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 4
+#define GSR_VERSION 5
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -71,6 +71,9 @@ typedef struct gsr_frame_plan {
     int32_t sort_result;                          /* out of gsr_forward_render: radix buffer holding lists  */
     int64_t instances_emitted;                    /* out of gsr_forward_render: instances actually binned;
                                                      -1 when the last chunk ran (its count is not read back)  */
+    int32_t binning_initialised;                  /* gsr_forward_preprocess was given the image workspace and has
+                                                     already reset the tile ranges / open flags in it        */
+    int32_t reserved;
 } gsr_frame_plan;
 
 typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */
@@ -116,9 +119,11 @@ int gsr_binning_size(const gsr_frame_desc *desc, int64_t num_rendered, size_t *b
 /* Stage 1 of `_C.rasterize_gaussians`: per-Gaussian preprocess (cull, project, EWA covariance,
  * SH colour), depth sort of the Gaussians, prefix sum of tiles touched in depth order, chunk plan.
  * Writes radii[P] and *plan_host (one host synchronisation; plan->num_rendered sizes the binning
- * workspace). */
+ * workspace).  image_ws (optional, may be NULL): when given, the per-frame reset of the tile ranges and open
+ * flags that stage 2 needs is enqueued here, BEFORE the host waits for the plan, so that it runs in the
+ * shadow of the readback. */
 int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g,
-                           void *geom_ws, int32_t *radii, gsr_frame_plan *plan_host, void *stream);
+                           void *geom_ws, void *image_ws, int32_t *radii, gsr_frame_plan *plan_host, void *stream);
 
 /* Stage 2 of `_C.rasterize_gaussians`: per depth chunk — emit (tile, instance) pairs into open tiles,
  * stable radix sort by tile, tile ranges, per-tile front-to-back blend continuing each pixel's state.

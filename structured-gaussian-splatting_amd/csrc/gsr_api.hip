@@ -181,7 +181,7 @@ int gsr_binning_size(const gsr_frame_desc *desc, int64_t num_rendered, size_t *b
 }
 
 int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws,
-                           int32_t *radii, gsr_frame_plan *plan, void *stream)
+                           void *image_ws, int32_t *radii, gsr_frame_plan *plan, void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
@@ -197,6 +197,11 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     if ((rc = launch_preprocess(f, *cam, *g, gw, radii, desc->prefiltered != 0, dbg, s))) return rc;
     if ((rc = launch_depth_order(f, gw, dbg, s))) return rc;
     if ((rc = launch_chunk_plan(f, gw, dbg, s))) return rc;
+    if (image_ws) {                                  // stage 2's reset of ranges / open flags, in the shadow of the readback
+        ImageWS iw = carve_image(image_ws, f);
+        if ((rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
+        plan->binning_initialised = 1;
+    }
     // The one host synchronisation of this stage: the plan (R sizes the binning workspace).
     Ctrl h;
     if ((rc = read_ctrl(gw.ctrl, &h, s))) return rc;
@@ -248,7 +253,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *
     }
     GeomWS gw = carve_geom(geom_ws, f.P);
     BinningWS bw = carve_binning(binning_ws, plan->num_rendered);
-    if ((rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
+    if (!plan->binning_initialised && (rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
     int sort_result = 0;
     uint64_t cand_before = 0;                       // upper bound of the instances earlier chunks can have emitted
     // Early stop: one control-block readback per chunk (~10 us of stream idle, measured); the chunk plan keeps

@@ -129,7 +129,7 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
         guess_key = (P, W, H, None if tile_rows is None else tuple(int(v) for v in tile_rows), device.index)
         guess = _binning_guess.get(guess_key, 0)
         binning = _workspace(guess, device) if guess > 0 else None
-        fr.plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device)
+        fr.plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device, image_ws=fr.image_ws)
         need = N.binning_size(fr.desc, fr.R)
         if binning is None or binning.numel() < need:
             binning = _workspace(need, device)

@@ -50,7 +50,8 @@ LAST_SHIFT = 26
 class FramePlan(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("num_chunks", C.c_int32),
                 ("chunk_rank_begin", C.c_int32 * (MAX_CHUNKS + 1)), ("chunk_instances_max", C.c_int64 * MAX_CHUNKS),
-                ("chunks_run", C.c_int32), ("sort_result", C.c_int32), ("instances_emitted", C.c_int64)]
+                ("chunks_run", C.c_int32), ("sort_result", C.c_int32), ("instances_emitted", C.c_int64),
+                ("binning_initialised", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DebugViews(C.Structure):
@@ -134,9 +135,9 @@ def binning_size(desc: FrameDesc, R: int) -> int:
     return b.value
 
 
-def forward_preprocess(desc, cam: Camera, g: Gaussians, geom_ws, radii, device) -> FramePlan:
+def forward_preprocess(desc, cam: Camera, g: Gaussians, geom_ws, radii, device, image_ws=None) -> FramePlan:
     plan = FramePlan()
-    _check(load().gsr_forward_preprocess(C.byref(desc), C.byref(cam), C.byref(g), _ptr(geom_ws), _ptr(radii),
+    _check(load().gsr_forward_preprocess(C.byref(desc), C.byref(cam), C.byref(g), _ptr(geom_ws), _ptr(image_ws), _ptr(radii),
                                          C.byref(plan), _stream(device)), "gsr_forward_preprocess")
     return plan
 

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(native):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gsrast.h but not exported"
     assert set(native.EXPORTS) == declared
-    assert lib.gsr_version() == 4
+    assert lib.gsr_version() == 5
 
 
 def test_argument_validation_without_gpu(native):
@@ -52,7 +52,7 @@ def test_argument_validation_without_gpu(native):
     cam = native.Camera(1, 1, 1, 1)
     gs = native.Gaussians(1, None, None, 1, 1, 1, None)
     plan = native.FramePlan()
-    rc = lib.gsr_forward_preprocess(C.byref(ok), C.byref(cam), C.byref(gs), C.c_void_p(1), C.c_void_p(1), C.byref(plan), None)
+    rc = lib.gsr_forward_preprocess(C.byref(ok), C.byref(cam), C.byref(gs), C.c_void_p(1), None, C.c_void_p(1), C.byref(plan), None)
     assert rc == -1 and b"shs / colors_precomp" in lib.gsr_last_error()
 
 
