@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 5
+#define GSR_VERSION 6
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -73,7 +73,7 @@ typedef struct gsr_frame_plan {
                                                      -1 when the last chunk ran (its count is not read back)  */
     int32_t binning_initialised;                  /* gsr_forward_preprocess was given the image workspace and has
                                                      already reset the tile ranges / open flags in it        */
-    int32_t reserved;
+    int32_t screen_prezeroed;                     /* set by gsr_backward_prepare: screen_grads is already all zero   */
 } gsr_frame_plan;
 
 typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */
@@ -104,6 +104,8 @@ typedef struct gsr_grads {       /* outputs of the backward; any may be NULL (no
     float *rotations;      /* [P,4]   */
     float *cov3D_precomp;  /* [P,6]   */
     float *shs_rest;       /* [P,M-1,3] raw mode only (then shs is [P,1,3]) */
+    int32_t prezeroed;     /* != 0: the caller has already zero-filled every non-NULL tensor above (gsr_backward_prepare);
+                              the sparse path of gsr_backward_geom then skips its own fill */
 } gsr_grads;
 
 int gsr_version(void);
@@ -137,6 +139,15 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *
  * when the forward went through its last chunk), so it is allocated when the backward runs and freed right
  * after it. */
 int gsr_backward_rows_size(const gsr_frame_desc *desc, const gsr_frame_plan *plan_host, size_t *rows_bytes);
+
+/* Optional: zero-fill the backward's outputs AHEAD of time, in one launch — typically right after
+ * gsr_forward_render returns, when the stream is idle while the host walks back through the caller's code to the
+ * loss.  screen_grads [P, GSR_SCREEN_GRAD_STRIDE] (may be NULL) and every non-NULL tensor of `grads` are
+ * cleared; plan_host->screen_prezeroed and grads->prezeroed are set so that gsr_backward_render /
+ * gsr_backward_geom skip their own fills.  Only worth calling when the sparse geometry backward will run
+ * (plan->chunk_rank_begin[plan->chunks_run] * 4 < P). */
+int gsr_backward_prepare(const gsr_frame_desc *desc, const gsr_gaussians *g, gsr_frame_plan *plan_host, float *screen_grads,
+                         gsr_grads *grads, void *stream);
 
 /* First half of `_C.rasterize_gaussians_backward`: reverse blend of the slab's tiles into rows_ws and the
  * deterministic per-Gaussian reduction -> screen_grads[P, GSR_SCREEN_GRAD_STRIDE]. */

@@ -296,6 +296,21 @@ int gsr_backward_rows_size(const gsr_frame_desc *desc, const gsr_frame_plan *pla
     return GSR_OK;
 }
 
+int gsr_backward_prepare(const gsr_frame_desc *desc, const gsr_gaussians *g, gsr_frame_plan *plan, float *screen_grads,
+                         gsr_grads *grads, void *stream)
+{
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!g || !plan || !grads) { set_error("gsr_backward_prepare: NULL argument"); return GSR_ERR_INVALID_ARGUMENT; }
+    if (desc->P == 0) return GSR_OK;
+    const FrameK f = make_frame(*desc);
+    ProfileScope prof("zero_outputs", (hipStream_t)stream);
+    if ((rc = launch_zero_outputs(f, *g, screen_grads, *grads, (hipStream_t)stream))) return rc;
+    if (screen_grads) plan->screen_prezeroed = 1;
+    grads->prezeroed = 1;
+    return GSR_OK;
+}
+
 int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const void *geom_ws, void *binning_ws,
                         const void *image_ws, void *rows_ws, const gsr_frame_plan *plan, const float *dL_dcolor,
                         float *screen_grads, void *stream)
@@ -322,7 +337,7 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     const int n_ranks = (plan->num_rendered > 0 && plan->chunks_run > 0) ? plan->chunk_rank_begin[plan->chunks_run] : 0;
     long long rows_upper = 0;
     for (int c = 0; c < plan->chunks_run && c < GSR_MAX_CHUNKS; ++c) rows_upper += plan->chunk_instances_max[c];
-    if ((rc = launch_reduce_rows(f, n_ranks, rows_upper, gw, bw, screen_grads, dbg, s))) return rc;
+    if ((rc = launch_reduce_rows(f, n_ranks, rows_upper, gw, bw, screen_grads, plan->screen_prezeroed != 0, dbg, s))) return rc;
     return GSR_OK;
 }
 

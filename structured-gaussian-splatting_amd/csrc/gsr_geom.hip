@@ -312,9 +312,9 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
 // ---- one launch that zero-fills up to nine output tensors (the sparse path's "memset"): the segments are laid end to
 // end in a virtual float index space; each thread clears a float4 where the 16 bytes lie inside one segment.
 struct ZeroSegs {
-    float *ptr[9];
-    size_t len[9];      // floats to clear in segment i
-    size_t end[9];      // exclusive end of segment i in the virtual index space (lengths rounded up to 4 floats)
+    float *ptr[10];
+    size_t len[10];      // floats to clear in segment i
+    size_t end[10];     // exclusive end of segment i in the virtual index space (lengths rounded up to 4 floats)
     int n;
 };
 
@@ -334,6 +334,33 @@ __global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z)
     }
 }
 
+// zero-fill of the backward's outputs in ONE launch: screen-space gradients (optional) + every wanted parameter gradient
+int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s)
+{
+    const size_t P = (size_t)f.P;
+    ZeroSegs z;
+    z.n = 0;
+    auto add = [&](float *ptr, size_t floats) {
+        if (ptr && floats) { z.ptr[z.n] = ptr; z.len[z.n] = floats; z.end[z.n] = (z.n ? z.end[z.n - 1] : 0) + ((floats + 3) & ~(size_t)3); ++z.n; }
+    };
+    add(screen, P * kRowFloats);
+    add(out.means3D, P * 3);
+    add(out.means2D, P * 3);
+    add(out.opacities, P);
+    if (g.colors_precomp) add(out.colors_precomp, P * 3);
+    if (!g.cov3D_precomp) { add(out.scales, P * 3); add(out.rotations, P * 4); }
+    if (g.cov3D_precomp) add(out.cov3D_precomp, P * 6);
+    if (g.shs) add(out.shs, P * 3 * (size_t)(g.raw ? 1 : f.M));
+    if (g.raw && f.M > 1) add(out.shs_rest, P * 3 * (size_t)(f.M - 1));
+    if (z.n == 0) return GSR_OK;
+    const size_t total = z.end[z.n - 1];
+    size_t blocks = (total / 4 + kGeomBlock - 1) / kGeomBlock / 4 + 1;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_zero_segments, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z);
+    GSR_LAUNCH_CHECK("zero_outputs", false, s);
+    return GSR_OK;
+}
+
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
                     const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s)
 {
@@ -341,26 +368,8 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
     if (n_ranks >= 0 && g0 == 0 && g1 == f.P && (long long)n_ranks * 4 < (long long)f.P) {
         // depth-complex frame: almost every gradient row is zero -> memset the outputs, then visit the binned prefix only
         ProfileScope prof("geom_bwd", s);
-        const size_t P = (size_t)f.P;
-        ZeroSegs z;
-        z.n = 0;
-        auto add = [&](float *ptr, size_t floats) {
-            if (ptr && floats) { z.ptr[z.n] = ptr; z.len[z.n] = floats; z.end[z.n] = (z.n ? z.end[z.n - 1] : 0) + ((floats + 3) & ~(size_t)3); ++z.n; }
-        };
-        add(out.means3D, P * 3);
-        add(out.means2D, P * 3);
-        add(out.opacities, P);
-        if (g.colors_precomp) add(out.colors_precomp, P * 3);
-        if (!g.cov3D_precomp) { add(out.scales, P * 3); add(out.rotations, P * 4); }
-        if (g.cov3D_precomp) add(out.cov3D_precomp, P * 6);
-        if (g.shs) add(out.shs, P * 3 * (size_t)(g.raw ? 1 : f.M));
-        if (g.raw && f.M > 1) add(out.shs_rest, P * 3 * (size_t)(f.M - 1));
-        if (z.n > 0) {
-            const size_t total = z.end[z.n - 1];
-            size_t blocks = (total / 4 + kGeomBlock - 1) / kGeomBlock / 4 + 1;
-            if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL(k_zero_segments, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z);
-        }
+        int rc0;
+        if (!out.prezeroed && (rc0 = launch_zero_outputs(f, g, nullptr, out, s))) return rc0;
         if (n_ranks > 0) {
             const int sgrid = (n_ranks + kGeomBlock - 1) / kGeomBlock;
 #define GSR_GS(DEG, RAW)                                                                                                     \

@@ -420,11 +420,11 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const ui
 }
 
 int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
-                       float *screen_grads, bool debug, hipStream_t s)
+                       float *screen_grads, bool prezeroed, bool debug, hipStream_t s)
 {
     if (f.P == 0) return GSR_OK;
     ProfileScope prof("reduce_rows", s);
-    GSR_HIP_CHECK(hipMemsetAsync(screen_grads, 0, (size_t)f.P * kRowFloats * sizeof(float), s));
+    if (!prezeroed) GSR_HIP_CHECK(hipMemsetAsync(screen_grads, 0, (size_t)f.P * kRowFloats * sizeof(float), s));
     if (n_ranks > 0) {
         // lanes per Gaussian: a whole wave when the processed Gaussians own many rows each (depth-complex scenes:
         // a few thousand screen-filling splats), eight otherwise

@@ -68,7 +68,7 @@ _binning_guess = {}        # (P, W, H, slab, device) -> bytes of the last binnin
 
 class _Frame:
     """Native handles of one forward pass, kept alive by autograd's ctx for the backward."""
-    __slots__ = ("desc", "cam", "keep", "plan", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device", "raw")
+    __slots__ = ("desc", "cam", "keep", "plan", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device", "raw", "pre")
 
     @property
     def R(self):
@@ -114,6 +114,7 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
                            N._ptr(rotations), N._ptr(cov3D_precomp), N._ptr(sh_rest), 1 if raw else 0)
     fr.keep = (cam_keep, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest)
     fr.raw = bool(raw)
+    fr.pre = None
     geom_bytes, image_bytes = N.workspace_sizes(fr.desc)
     fr.geom_ws = _workspace(geom_bytes, device)
     fr.image_ws = _workspace(image_bytes, device)
@@ -145,7 +146,11 @@ def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.T
     """K7 + deterministic per-Gaussian reduction -> screen-space gradients [P, 12]."""
     P = fr.desc.P
     grad_color = _f32c(grad_color, fr.device)
-    screen = torch.empty(max(P, 1), N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=fr.device)
+    pre_screen = fr.pre.pop("screen", None) if fr.pre is not None else None        # zero-filled after the forward; used once
+    screen = pre_screen if pre_screen is not None else torch.empty(max(P, 1), N.SCREEN_GRAD_STRIDE, dtype=torch.float32,
+                                                                   device=fr.device)
+    if pre_screen is None:
+        fr.plan.screen_prezeroed = 0
     if grad_color is None:
         return screen.zero_()[:P]
     with torch.cuda.device(fr.device):
@@ -153,7 +158,41 @@ def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.T
         rows = _workspace(N.backward_rows_size(fr.desc, fr.plan), fr.device)
         N.backward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, rows, fr.plan, grad_color, screen,
                           fr.device)
+        fr.plan.screen_prezeroed = 0
     return screen[:P]
+
+
+def _alloc_grads(fr: "_Frame", needs, alloc):
+    """Gradient tensors of one frame (None where not wanted / not applicable) and their gsr_grads struct."""
+    P, M, dev = fr.desc.P, fr.M, fr.device
+    (_, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest) = fr.keep
+
+    def mk(flag, present, *shape):
+        return alloc(*shape, dtype=torch.float32, device=dev) if (flag and present) else None
+    t = (mk(needs[0], True, P, 3), mk(needs[1], True, P, 3), mk(needs[2], sh is not None, P, 1 if fr.raw else M, 3),
+         mk(needs[3], colors_precomp is not None, P, 3), mk(needs[4], True, P, 1), mk(needs[5], scales is not None, P, 3),
+         mk(needs[6], rotations is not None, P, 4), mk(needs[7], cov3D_precomp is not None, P, 6),
+         mk(fr.raw and len(needs) > 8 and needs[8], sh_rest is not None, P, M - 1, 3))
+    grads = N.Grads(N._ptr(t[0]), N._ptr(t[1]), N._ptr(t[2]), N._ptr(t[3]), N._ptr(t[4]), N._ptr(t[5]), N._ptr(t[6]),
+                    N._ptr(t[7]), N._ptr(t[8]), 0)
+    return t, grads
+
+
+def prepare_backward(fr: "_Frame", needs) -> None:
+    """Called right after the forward when a backward will follow: the stream is idle while the host walks back
+    through the caller's code to the loss, so the backward's zero fills (screen-space gradients + the parameter
+    gradients of the sparse geometry backward, ~280 MB at 1e6 Gaussians) are enqueued NOW, in one launch."""
+    P, plan = fr.desc.P, fr.plan
+    if P == 0 or plan.num_rendered <= 0 or plan.chunks_run <= 0 or not any(needs):
+        return
+    if int(plan.chunk_rank_begin[plan.chunks_run]) * 4 >= P:
+        return                                  # the dense geometry backward writes every row itself
+    needs = tuple(bool(x) for x in needs)
+    tensors, grads = _alloc_grads(fr, needs, torch.empty)
+    screen = torch.empty(P, N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=fr.device)
+    with torch.cuda.device(fr.device):
+        N.backward_prepare(fr.desc, fr.gauss, plan, screen, grads, fr.device)
+    fr.pre = {"needs": needs, "tensors": tensors, "grads": grads, "screen": screen}
 
 
 def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int = 0, g1: Optional[int] = None,
@@ -161,25 +200,15 @@ def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int =
     """K8 + K9 on Gaussians [g0, g1).  `needs` = (means3D, means2D, sh, colors, opacities, scales, rotations,
     cov3D[, sh_rest]) booleans.  Returns the 8 gradient tensors (None where not needed / not applicable); for a
     raw-mode frame 9: sh is then d/d_features_dc [P,1,3] and the ninth d/d_features_rest [P,M-1,3]."""
-    P, M, dev = fr.desc.P, fr.M, fr.device
+    P, dev = fr.desc.P, fr.device
     g1 = P if g1 is None else g1
-    (_, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest) = fr.keep
     partial = (g0, g1) != (0, P)
-    alloc = torch.zeros if partial else torch.empty
-
-    def mk(flag, present, *shape):
-        return alloc(*shape, dtype=torch.float32, device=dev) if (flag and present) else None
-    g_means3D = mk(needs[0], True, P, 3)
-    g_means2D = mk(needs[1], True, P, 3)
-    g_sh = mk(needs[2], sh is not None, P, 1 if fr.raw else M, 3)
-    g_rest = mk(fr.raw and len(needs) > 8 and needs[8], sh_rest is not None, P, M - 1, 3)
-    g_col = mk(needs[3], colors_precomp is not None, P, 3)
-    g_op = mk(needs[4], True, P, 1)
-    g_sc = mk(needs[5], scales is not None, P, 3)
-    g_rot = mk(needs[6], rotations is not None, P, 4)
-    g_cov = mk(needs[7], cov3D_precomp is not None, P, 6)
-    grads = N.Grads(N._ptr(g_means3D), N._ptr(g_means2D), N._ptr(g_sh), N._ptr(g_col), N._ptr(g_op), N._ptr(g_sc),
-                    N._ptr(g_rot), N._ptr(g_cov), N._ptr(g_rest))
+    pre, fr.pre = fr.pre, None
+    if pre is not None and not partial and tuple(bool(x) for x in needs) == pre["needs"]:
+        tensors, grads = pre["tensors"], pre["grads"]                  # allocated and zero-filled right after the forward; used once
+    else:
+        tensors, grads = _alloc_grads(fr, needs, torch.zeros if partial else torch.empty)
+    g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, g_rest = tensors
     if P > 0 and g1 > g0:
         with torch.cuda.device(dev):
             if binned_ranks is None:        # gradients of this very frame: its own binned depth prefix
@@ -215,6 +244,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
         else:
             color, radii, frame = rasterize_forward(*args, rs)
+            prepare_backward(frame, tuple(ctx.needs_input_grad[:8]))
         ctx.frame = frame
         ctx.raster_settings = rs
         ctx.shapes = (means2D.shape, opacities.shape)
@@ -263,6 +293,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                                 sh_rest=features_rest, raw=True)
         if rs.debug:
             torch.cuda.synchronize(xyz.device)
+        n = ctx.needs_input_grad       # xyz, means2D, f_dc, f_rest, opacity, scales, rotations
+        prepare_backward(frame, (n[0], n[1], n[2], False, n[4], n[5], n[6], False, n[3]))
         ctx.frame = frame
         ctx.shapes = (means2D.shape, opacity_logits.shape)
         ctx.mark_non_differentiable(radii)

@@ -40,7 +40,7 @@ class Gaussians(C.Structure):
 class Grads(C.Structure):
     _fields_ = [("means3D", _f32p), ("means2D", _f32p), ("shs", _f32p), ("colors_precomp", _f32p),
                 ("opacities", _f32p), ("scales", _f32p), ("rotations", _f32p), ("cov3D_precomp", _f32p),
-                ("shs_rest", _f32p)]
+                ("shs_rest", _f32p), ("prezeroed", C.c_int32)]
 
 
 MAX_CHUNKS = 8
@@ -51,7 +51,7 @@ class FramePlan(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("num_chunks", C.c_int32),
                 ("chunk_rank_begin", C.c_int32 * (MAX_CHUNKS + 1)), ("chunk_instances_max", C.c_int64 * MAX_CHUNKS),
                 ("chunks_run", C.c_int32), ("sort_result", C.c_int32), ("instances_emitted", C.c_int64),
-                ("binning_initialised", C.c_int32), ("reserved", C.c_int32)]
+                ("binning_initialised", C.c_int32), ("screen_prezeroed", C.c_int32)]
 
 
 class DebugViews(C.Structure):
@@ -61,7 +61,7 @@ class DebugViews(C.Structure):
 
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
-           "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
+           "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward",
            "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_densify_stats")
 
@@ -151,6 +151,11 @@ def backward_rows_size(desc: FrameDesc, plan: FramePlan) -> int:
     b = C.c_size_t(0)
     _check(load().gsr_backward_rows_size(C.byref(desc), C.byref(plan), C.byref(b)), "gsr_backward_rows_size")
     return b.value
+
+
+def backward_prepare(desc, g: Gaussians, plan: FramePlan, screen_grads, grads: Grads, device):
+    _check(load().gsr_backward_prepare(C.byref(desc), C.byref(g), C.byref(plan), _ptr(screen_grads), C.byref(grads),
+                                       _stream(device)), "gsr_backward_prepare")
 
 
 def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, rows_ws, plan: FramePlan, dL_dcolor, screen_grads,
