@@ -105,7 +105,8 @@ def main():
             out = render(cam, model, pipe, bg)
         else:
             out = sharded.render(cam, model, pipe, bg)
-        loss = training_loss(out["render"], gt)
+        # same loss; on N > 1 every rank evaluates the terms of its own rows (slab-local, one 8-byte all-reduce)
+        loss = training_loss(out["render"], gt) if sharded is None else sharded.training_loss(out["render"], gt)
         loss.backward()
         return out
 

@@ -198,6 +198,17 @@ int gsr_loss_l1_ssim_forward(int32_t channels, int32_t height, int32_t width, fl
 int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *upstream,
                               const float *image, const float *target, const void *workspace, float *grad_image,
                               void *stream);
+/* Multi-GPU slab variants (SURVEY 8e "slab-local loss"): this rank owns image rows [row_begin, row_end) of a
+ * full-size image whose rows within 10 of the slab are valid.  forward_rows writes out2 = (sum |image - target|,
+ * sum of the SSIM map) over the slab's rows — un-normalised: the caller adds the ranks' pairs and forms
+ * loss = (1 - lambda) * l1 / n + lambda * (1 - ssim / n), n = channels * height * width — and the derivative
+ * maps of the slab plus 5 rows either side.  backward_rows writes grad_image rows [row_begin, row_end) only:
+ * the full d loss / d image of those rows (window contributions from the neighbouring slabs included). */
+int gsr_loss_l1_ssim_forward_rows(int32_t channels, int32_t height, int32_t width, const float *image, const float *target,
+                                  void *workspace, float *out2, int32_t row_begin, int32_t row_end, void *stream);
+int gsr_loss_l1_ssim_backward_rows(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *upstream,
+                                   const float *image, const float *target, const void *workspace, float *grad_image,
+                                   int32_t row_begin, int32_t row_end, void *stream);
 
 /* ---- `simple_knn._C.distCUDA2` (scene/gaussian_model.py:144-145): mean of the squared
  * distances from each point to its 3 nearest other points (exact), used once to initialise the scales.

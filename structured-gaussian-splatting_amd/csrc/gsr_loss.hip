@@ -28,8 +28,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));     // packed-fp32 operan
 // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so XCD x gets the contiguous run of
 // (channel, tile row, tile column) items [start(x), start(x) + count(x)): neighbouring tiles, whose 5-px halos
 // overlap, then share one L2 instead of fetching the halo from HBM once per XCD.
+// Row ranges of a launch (multi-GPU slabs; the whole image is {0, H, 0, H, 0}): `sum` rows enter the L1 / SSIM
+// sums and receive gradients, `map` rows get their SSIM derivative maps written (the slab plus the 5 rows either side
+// that the backward's window reaches), tile rows start at ty0.
+struct LossRows { int sum_b, sum_e, map_b, map_e, ty0; };
+
 struct LossTile { int ch, x0, y0, bid; };
-__device__ __forceinline__ LossTile loss_tile(int tiles_x, int tiles_y, int channels)
+__device__ __forceinline__ LossTile loss_tile(int tiles_x, int tiles_y, int channels, int ty0 = 0)
 {
     const int n = tiles_x * tiles_y * channels;
     const int b = (int)blockIdx.x;
@@ -39,7 +44,7 @@ __device__ __forceinline__ LossTile loss_tile(int tiles_x, int tiles_y, int chan
     o.bid = t;
     o.ch = t / (tiles_x * tiles_y);
     const int rem = t - o.ch * tiles_x * tiles_y;
-    o.y0 = (rem / tiles_x) * kLT;
+    o.y0 = (ty0 + rem / tiles_x) * kLT;
     o.x0 = (rem % tiles_x) * kLT;
     return o;
 }
@@ -119,7 +124,8 @@ constexpr int kRowItems = kLI * (kLT / kRowW);     // 168
 constexpr int kColH = 4;                // outputs per thread in the column pass
 
 template <bool VEC>
-__global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, Win win, const float *__restrict__ a, const float *__restrict__ b,
+__global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, LossRows rows, int tiles_y, Win win, const float *__restrict__ a,
+                                                      const float *__restrict__ b,
                                                       float *__restrict__ d_mu, float *__restrict__ d_eaa, float *__restrict__ d_eab,
                                                       float *__restrict__ partial_ssim, float *__restrict__ partial_l1)
 {
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, Win w
     float (*sa)[kLP] = reinterpret_cast<float (*)[kLP]>(lds);
     float (*sb)[kLP] = reinterpret_cast<float (*)[kLP]>(lds + kLI * kLP);
     float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
-    const LossTile lt = loss_tile((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    const LossTile lt = loss_tile((W + kLT - 1) / kLT, tiles_y, C, rows.ty0);
     const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
     const size_t plane = (size_t)ch * H * W;
     {
@@ -202,14 +208,16 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, Win w
     for (int k = 0; k < kColH; ++k) {
         const int y = y0 + rr0 + k, x = x0 + cc;
         const float mu1 = acc[0][k], mu2 = acc[1][k], eaa = acc[2][k], ebb = acc[3][k], eab = acc[4][k];
-        if (y < H && x < W) {
+        if (y < H && x < W && y >= rows.map_b && y < rows.map_e) {
             const float s1 = eaa - mu1 * mu1, s2 = ebb - mu2 * mu2, s12 = eab - mu1 * mu2;
             const float A1 = 2.f * mu1 * mu2 + kC1, A2 = 2.f * s12 + kC2;
             const float B1 = mu1 * mu1 + mu2 * mu2 + kC1, B2 = s1 + s2 + kC2;
             const float inv = 1.f / (B1 * B2);
             const float mm = A1 * A2 * inv;
-            s_ssim += mm;
-            s_l1 += fabsf(ca[k] - cbv[k]);
+            if (y >= rows.sum_b && y < rows.sum_e) {
+                s_ssim += mm;
+                s_l1 += fabsf(ca[k] - cbv[k]);
+            }
             if (d_mu) {
                 const size_t p = plane + (size_t)y * W + x;
                 d_mu[p] = 2.f * mu2 * (A2 - A1) * inv - 2.f * mu1 * mm * (B2 - B1) * inv;
@@ -226,7 +234,8 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, Win w
     }
 }
 
-__global__ __launch_bounds__(kLBlock) void k_loss_finish(int nblocks, float inv_count, float lambda, const float *__restrict__ partial_ssim,
+__global__ __launch_bounds__(kLBlock) void k_loss_finish(int nblocks, float inv_count, float lambda, int raw_sums,
+                                                         const float *__restrict__ partial_ssim,
                                                          const float *__restrict__ partial_l1, float *__restrict__ out /*[3]*/)
 {
     __shared__ float red[4];
@@ -242,17 +251,20 @@ __global__ __launch_bounds__(kLBlock) void k_loss_finish(int nblocks, float inv_
 #pragma unroll
         for (int u = 0; u < 8; ++u) { s += ps[u]; l += pl[u]; }                // fixed order: deterministic
     }
-    const float ts = block_sum(s, red) * inv_count;
-    const float tl = block_sum(l, red) * inv_count;
+    const float ts = block_sum(s, red) * (raw_sums ? 1.f : inv_count);
+    const float tl = block_sum(l, red) * (raw_sums ? 1.f : inv_count);
     if (threadIdx.x == 0) {
-        out[0] = (1.f - lambda) * tl + lambda * (1.f - ts);
-        out[1] = tl;
-        out[2] = ts;
+        if (raw_sums) { out[0] = tl; out[1] = ts; }      // slab: un-normalised sums, the caller adds the ranks' pairs
+        else {
+            out[0] = (1.f - lambda) * tl + lambda * (1.f - ts);
+            out[1] = tl;
+            out[2] = ts;
+        }
     }
 }
 
 template <bool VEC>
-__global__ __launch_bounds__(kLBlock) void k_loss_bwd(int C, int H, int W, Win win, float inv_count, float lambda,
+__global__ __launch_bounds__(kLBlock) void k_loss_bwd(int C, int H, int W, LossRows rows, int tiles_y, Win win, float inv_count, float lambda,
                                                       const float *__restrict__ upstream, const float *__restrict__ a,
                                                       const float *__restrict__ b, const float *__restrict__ d_mu,
                                                       const float *__restrict__ d_eaa, const float *__restrict__ d_eab,
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int C, int H, int W, Win w
     __shared__ __attribute__((aligned(16))) float lds[kStageFloats];   // staged maps, then (over the same bytes) row-filtered maps
     float (*sm)[kLI][kLP] = reinterpret_cast<float (*)[kLI][kLP]>(lds);
     float (*hz)[kLI][kLT + 1] = reinterpret_cast<float (*)[kLI][kLT + 1]>(lds);
-    const LossTile lt = loss_tile((W + kLT - 1) / kLT, (H + kLT - 1) / kLT, C);
+    const LossTile lt = loss_tile((W + kLT - 1) / kLT, tiles_y, C, rows.ty0);
     const int ch = lt.ch, x0 = lt.x0, y0 = lt.y0;
     const size_t plane = (size_t)ch * H * W;
     {
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int C, int H, int W, Win w
 #pragma unroll
     for (int k = 0; k < kColH; ++k) {
         const int y = y0 + rr0 + k, x = x0 + cc;
-        if (y >= H || x >= W) continue;
+        if (y >= H || x >= W || y < rows.sum_b || y >= rows.sum_e) continue;
         const size_t p = plane + (size_t)y * W + x;
         const float va = a[p], vb = b[p];
         const float d = va - vb;
@@ -352,57 +364,102 @@ static void carve_loss(void *ws, int C, int H, int W, float **d_mu, float **d_ea
     *pl = (float *)b;
 }
 
-int gsr_loss_l1_ssim_forward(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *image,
-                             const float *target, void *workspace, float *out3, void *stream)
+// rows = NULL: whole image, out = (loss, l1, ssim).  rows given: slab, out = (sum |a - b|, sum SSIM) over the slab's rows.
+static int loss_forward_impl(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *image,
+                             const float *target, void *workspace, float *out, const int32_t *rows, hipStream_t s)
 {
-    if (channels <= 0 || height <= 0 || width <= 0 || !image || !target || !workspace || !out3) {
+    if (channels <= 0 || height <= 0 || width <= 0 || !image || !target || !workspace || !out) {
         set_error("gsr_loss_l1_ssim_forward: bad argument");
         return GSR_ERR_INVALID_ARGUMENT;
     }
-    hipStream_t s = (hipStream_t)stream;
+    LossRows lr{0, height, 0, height, 0};
+    if (rows) {
+        if (rows[0] < 0 || rows[1] > height || rows[0] > rows[1]) { set_error("loss rows [%d, %d) outside the image", rows[0], rows[1]); return GSR_ERR_INVALID_ARGUMENT; }
+        lr.sum_b = rows[0]; lr.sum_e = rows[1];
+        lr.map_b = rows[0] - kLH > 0 ? rows[0] - kLH : 0;
+        lr.map_e = rows[1] + kLH < height ? rows[1] + kLH : height;
+        lr.ty0 = lr.map_b / kLT;
+    }
     float *d_mu, *d_eaa, *d_eab, *ps, *pl;
     carve_loss(workspace, channels, height, width, &d_mu, &d_eaa, &d_eab, &ps, &pl);
-    const int nblocks = ((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT) * channels;
-    const dim3 grid(nblocks);
+    const int tiles_y = lr.map_e > lr.map_b ? (lr.map_e + kLT - 1) / kLT - lr.ty0 : 0;
+    const int nblocks = ((width + kLT - 1) / kLT) * tiles_y * channels;
     const float inv_count = 1.f / ((float)channels * (float)height * (float)width);
     const Win win = make_window();
-    {
-        ProfileScope prof("loss_fwd", s);
+    ProfileScope prof("loss_fwd", s);
+    if (nblocks > 0) {
+        const dim3 grid(nblocks);
         const bool vec = width % 4 == 0 && ((uintptr_t)image % 16 == 0) && ((uintptr_t)target % 16 == 0);
-        if (vec) hipLaunchKernelGGL(k_loss_fwd<true>, grid, dim3(kLBlock), 0, s, channels, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
-        else hipLaunchKernelGGL(k_loss_fwd<false>, grid, dim3(kLBlock), 0, s, channels, height, width, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
-        hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(kLBlock), 0, s, nblocks, inv_count, lambda_dssim, ps, pl, out3);
-        GSR_LAUNCH_CHECK("loss_fwd", false, s);
+        if (vec) hipLaunchKernelGGL(k_loss_fwd<true>, grid, dim3(kLBlock), 0, s, channels, height, width, lr, tiles_y, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
+        else hipLaunchKernelGGL(k_loss_fwd<false>, grid, dim3(kLBlock), 0, s, channels, height, width, lr, tiles_y, win, image, target, d_mu, d_eaa, d_eab, ps, pl);
     }
+    hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(kLBlock), 0, s, nblocks, inv_count, lambda_dssim, rows ? 1 : 0, ps, pl, out);
+    GSR_LAUNCH_CHECK("loss_fwd", false, s);
     return GSR_OK;
 }
 
-int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *upstream,
-                              const float *image, const float *target, const void *workspace, float *grad_image, void *stream)
+static int loss_backward_impl(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *upstream,
+                              const float *image, const float *target, const void *workspace, float *grad_image,
+                              const int32_t *rows, hipStream_t s)
 {
     if (channels <= 0 || height <= 0 || width <= 0 || !image || !target || !workspace || !grad_image) {
         set_error("gsr_loss_l1_ssim_backward: bad argument");
         return GSR_ERR_INVALID_ARGUMENT;
     }
-    hipStream_t s = (hipStream_t)stream;
+    LossRows lr{0, height, 0, height, 0};
+    if (rows) {
+        if (rows[0] < 0 || rows[1] > height || rows[0] > rows[1]) { set_error("loss rows [%d, %d) outside the image", rows[0], rows[1]); return GSR_ERR_INVALID_ARGUMENT; }
+        lr.sum_b = rows[0]; lr.sum_e = rows[1];
+        lr.map_b = lr.sum_b; lr.map_e = lr.sum_e;
+        lr.ty0 = lr.sum_b / kLT;
+    }
+    const int tiles_y = lr.sum_e > lr.sum_b ? (lr.sum_e + kLT - 1) / kLT - lr.ty0 : 0;
+    if (tiles_y == 0) return GSR_OK;
     float *d_mu, *d_eaa, *d_eab, *ps, *pl;
     carve_loss(const_cast<void *>(workspace), channels, height, width, &d_mu, &d_eaa, &d_eab, &ps, &pl);
-    const dim3 grid(((width + kLT - 1) / kLT) * ((height + kLT - 1) / kLT) * channels);
+    const dim3 grid(((width + kLT - 1) / kLT) * tiles_y * channels);
     const float inv_count = 1.f / ((float)channels * (float)height * (float)width);
     const Win win = make_window();
-    {
-        ProfileScope prof("loss_bwd", s);
-        // the derivative maps are 256-byte aligned planes of the workspace: float4 rows whenever the width allows
-        const bool vec = width % 4 == 0 && ((uintptr_t)workspace % 16 == 0) && (((size_t)channels * height * width * 4) % 16 == 0);
-        if (vec)
-            hipLaunchKernelGGL(k_loss_bwd<true>, grid, dim3(kLBlock), 0, s, channels, height, width, win, inv_count, lambda_dssim, upstream, image,
-                               target, d_mu, d_eaa, d_eab, grad_image);
-        else
-            hipLaunchKernelGGL(k_loss_bwd<false>, grid, dim3(kLBlock), 0, s, channels, height, width, win, inv_count, lambda_dssim, upstream, image,
-                               target, d_mu, d_eaa, d_eab, grad_image);
-        GSR_LAUNCH_CHECK("loss_bwd", false, s);
-    }
+    ProfileScope prof("loss_bwd", s);
+    // the derivative maps are 256-byte aligned planes of the workspace: float4 rows whenever the width allows
+    const bool vec = width % 4 == 0 && ((uintptr_t)workspace % 16 == 0) && (((size_t)channels * height * width * 4) % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_loss_bwd<true>, grid, dim3(kLBlock), 0, s, channels, height, width, lr, tiles_y, win, inv_count, lambda_dssim,
+                           upstream, image, target, d_mu, d_eaa, d_eab, grad_image);
+    else
+        hipLaunchKernelGGL(k_loss_bwd<false>, grid, dim3(kLBlock), 0, s, channels, height, width, lr, tiles_y, win, inv_count, lambda_dssim,
+                           upstream, image, target, d_mu, d_eaa, d_eab, grad_image);
+    GSR_LAUNCH_CHECK("loss_bwd", false, s);
     return GSR_OK;
+}
+
+int gsr_loss_l1_ssim_forward(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *image,
+                             const float *target, void *workspace, float *out3, void *stream)
+{
+    return loss_forward_impl(channels, height, width, lambda_dssim, image, target, workspace, out3, nullptr, (hipStream_t)stream);
+}
+
+int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *upstream,
+                              const float *image, const float *target, const void *workspace, float *grad_image, void *stream)
+{
+    return loss_backward_impl(channels, height, width, lambda_dssim, upstream, image, target, workspace, grad_image, nullptr,
+                              (hipStream_t)stream);
+}
+
+int gsr_loss_l1_ssim_forward_rows(int32_t channels, int32_t height, int32_t width, const float *image, const float *target,
+                                  void *workspace, float *out2, int32_t row_begin, int32_t row_end, void *stream)
+{
+    const int32_t rows[2] = {row_begin, row_end};
+    return loss_forward_impl(channels, height, width, 0.f, image, target, workspace, out2, rows, (hipStream_t)stream);
+}
+
+int gsr_loss_l1_ssim_backward_rows(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *upstream,
+                                   const float *image, const float *target, const void *workspace, float *grad_image,
+                                   int32_t row_begin, int32_t row_end, void *stream)
+{
+    const int32_t rows[2] = {row_begin, row_end};
+    return loss_backward_impl(channels, height, width, lambda_dssim, upstream, image, target, workspace, grad_image, rows,
+                              (hipStream_t)stream);
 }
 
 }  // extern "C"

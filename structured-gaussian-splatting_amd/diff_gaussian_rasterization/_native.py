@@ -62,7 +62,7 @@ class DebugViews(C.Structure):
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
            "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
-           "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward",
+           "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows",
            "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_densify_stats")
 
 _lib = None
@@ -234,6 +234,21 @@ def loss_backward(image, target, lam, upstream, workspace, grad_image):
     _check(load().gsr_loss_l1_ssim_backward(C.c_int32(Cn), C.c_int32(H), C.c_int32(W), C.c_float(lam), _ptr(upstream),
                                             _ptr(image), _ptr(target), _ptr(workspace), _ptr(grad_image),
                                             _stream(image.device)), "gsr_loss_l1_ssim_backward")
+
+
+def loss_forward_rows(image, target, workspace, out2, row_begin, row_end):
+    Cn, H, W = image.shape
+    _check(load().gsr_loss_l1_ssim_forward_rows(C.c_int32(Cn), C.c_int32(H), C.c_int32(W), _ptr(image), _ptr(target),
+                                                _ptr(workspace), _ptr(out2), C.c_int32(row_begin), C.c_int32(row_end),
+                                                _stream(image.device)), "gsr_loss_l1_ssim_forward_rows")
+
+
+def loss_backward_rows(image, target, lam, upstream, workspace, grad_image, row_begin, row_end):
+    Cn, H, W = image.shape
+    _check(load().gsr_loss_l1_ssim_backward_rows(C.c_int32(Cn), C.c_int32(H), C.c_int32(W), C.c_float(lam), _ptr(upstream),
+                                                 _ptr(image), _ptr(target), _ptr(workspace), _ptr(grad_image),
+                                                 C.c_int32(row_begin), C.c_int32(row_end), _stream(image.device)),
+           "gsr_loss_l1_ssim_backward_rows")
 
 
 def debug_sort_pairs(keys: torch.Tensor, vals: torch.Tensor, end_bit: int, count_on_device: bool = False):

@@ -255,6 +255,21 @@ class ShardedRenderer:
         self.row_weights = row_weights
         self.backward_mode = backward_mode
 
+    def pixel_rows(self, H: int):
+        """This rank's image rows [y0, y1) for an H-row frame (its tile-row slab in pixels)."""
+        a, b = self.slabs((H + 15) // 16)[self.comm.rank]
+        return min(a * 16, H), min(b * 16, H)
+
+    def training_loss(self, image, gt, lambda_dssim: float = 0.2):
+        """train.py:104-105 for a frame rendered by this renderer: every rank evaluates the L1 / D-SSIM terms of its
+        own rows (fused kernels) and the ranks' partial sums are added; the gradient comes back for the rank's rows only.
+        Same value as loss_utils.training_loss on the full frame (summation order aside)."""
+        import loss_utils
+        if not image.is_cuda:
+            return loss_utils.training_loss(image, gt, lambda_dssim)
+        return loss_utils.training_loss_rows(image, gt, lambda_dssim, self.pixel_rows(int(image.shape[1])),
+                                             lambda t: self.comm.all_reduce_sum(t))
+
     def slabs(self, Gy: int):
         return slab_bounds(Gy, self.comm.world, self.row_weights if self.row_weights and len(self.row_weights) == Gy else None)
 

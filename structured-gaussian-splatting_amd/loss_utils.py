@@ -76,6 +76,44 @@ class _FusedL1SSIM(torch.autograd.Function):
         return grad, None, None
 
 
+class _FusedL1SSIMRows(torch.autograd.Function):
+    """Slab-local form for multi-GPU: this rank evaluates the loss terms of its own image rows
+    [y0, y1) — the image must be valid 10 rows beyond them, which the gathered frame is — the ranks' two partial sums are
+    added with one 8-byte all-reduce, and the backward returns d loss / d image for the rank's rows only (zeros
+    elsewhere): exactly the rows whose tiles this rank back-propagates."""
+
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim, y0, y1, all_reduce_sum):
+        from diff_gaussian_rasterization import _native as N
+        img = image.contiguous() if image.dtype == torch.float32 else image.float().contiguous()
+        tgt = gt.detach().contiguous() if gt.dtype == torch.float32 else gt.detach().float().contiguous()
+        ws = torch.empty(N.loss_workspace_size(*img.shape), dtype=torch.uint8, device=img.device)
+        out2 = torch.empty(2, dtype=torch.float32, device=img.device)
+        with torch.cuda.device(img.device):
+            N.loss_forward_rows(img, tgt, ws, out2, int(y0), int(y1))
+        sums = all_reduce_sum(out2)
+        n = float(img.numel())
+        ctx.save_for_backward(img, tgt, ws)
+        ctx.lam, ctx.rows = float(lambda_dssim), (int(y0), int(y1))
+        return (1.0 - ctx.lam) * sums[0] / n + ctx.lam * (1.0 - sums[1] / n)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from diff_gaussian_rasterization import _native as N
+        img, tgt, ws = ctx.saved_tensors
+        grad = torch.zeros_like(img)
+        up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(img.device):
+            N.loss_backward_rows(img, tgt, ctx.lam, up, ws, grad, ctx.rows[0], ctx.rows[1])
+        return grad, None, None, None, None, None
+
+
+def training_loss_rows(image, gt, lambda_dssim, rows, all_reduce_sum):
+    """Multi-GPU counterpart of training_loss(): `rows` = this rank's image rows [y0, y1), `all_reduce_sum` a callable
+    that sums a small device tensor over the ranks (ShardedRenderer.training_loss passes its communicator's)."""
+    return _FusedL1SSIMRows.apply(image, gt, lambda_dssim, rows[0], rows[1], all_reduce_sum)
+
+
 def training_loss(image, gt, lambda_dssim: float = 0.2):
     """train.py:104-105.  On a HIP device: the fused kernels (image must be [C,H,W]); on the CPU: torch ops."""
     if image.is_cuda and image.dim() == 3:

@@ -22,22 +22,37 @@ def _scene():
 
 
 def _render(rank, world, mode):
+    """mode: a backward_mode of ShardedRenderer, or "loss": default exchange + the train.py loss (slab-local on the ranks)."""
     from gaussian_params import GaussianParams, Pipe
     from gaussian_renderer import render
+    from loss_utils import training_loss
     dev = "cuda:0"
     scene, cam = _scene()
     cam = cam.to(dev)
     model = GaussianParams(scene.to(dev)).to(dev)
     bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
+    gt = torch.rand(3, 304, 400, generator=torch.Generator().manual_seed(77)).to(dev)
+    loss_value = None
     if world == 1:
         out = render(cam, model, Pipe(), bg)
+        if mode == "loss":
+            loss = training_loss(out["render"], gt)
     else:
         from diff_gaussian_rasterization.sharded import ShardedRenderer
-        out = ShardedRenderer(dist, world, rank, backward_mode=mode).render(cam, model, Pipe(), bg)
-    out["render"].backward(S.make_grad_image(400, 304, 8).to(dev))
+        sr = ShardedRenderer(dist, world, rank, backward_mode="allreduce_screen" if mode == "loss" else mode)
+        out = sr.render(cam, model, Pipe(), bg)
+        if mode == "loss":
+            loss = sr.training_loss(out["render"], gt)
+    if mode == "loss":
+        loss.backward()
+        loss_value = float(loss.detach())
+    else:
+        out["render"].backward(S.make_grad_image(400, 304, 8).to(dev))
     torch.cuda.synchronize()
     res = dict(image=out["render"].detach().cpu().numpy(), radii=out["radii"].cpu().numpy(),
                means2D=out["viewspace_points"].grad.cpu().numpy())
+    if loss_value is not None:
+        res["loss"] = np.float64(loss_value)
     res.update({n: p.grad.cpu().numpy() for n, p in model.named_parameters()})
     return res
 
@@ -51,7 +66,7 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "allreduce_screen"), (3, "allreduce_screen"), (2, "reduce_scatter")])
+@pytest.mark.parametrize("world,mode", [(2, "allreduce_screen"), (3, "allreduce_screen"), (2, "reduce_scatter"), (3, "loss")])
 def test_native_slabs_in_separate_processes_equal_single_render(world, mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
@@ -72,3 +87,34 @@ def test_native_slabs_in_separate_processes_equal_single_render(world, mode):
                 continue
             scale = max(np.abs(want[k]).max(), 1e-30)
             assert np.abs(got[k] - want[k]).max() <= 5e-6 * scale, (r, k, np.abs(got[k] - want[k]).max(), scale)
+
+
+def test_slab_local_loss_pieces_add_up_to_the_full_loss():
+    """gsr_loss_l1_ssim_forward_rows / backward_rows in one process: the partial sums of three slabs (16-row aligned, as the
+    renderer's are, and one ragged) add up to the full-frame sums, and the slabs' gradient rows tile the full gradient."""
+    from diff_gaussian_rasterization import _native as N
+    import loss_utils
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    for (H, W, cuts) in ((304, 400, (0, 96, 208, 304)), (67, 101, (0, 16, 48, 67)), (40, 36, (0, 0, 32, 40))):
+        a = torch.rand(3, H, W, generator=g).to(dev).requires_grad_(True)
+        b = torch.rand(3, H, W, generator=g).to(dev)
+        full = loss_utils.training_loss(a, b, 0.2)
+        full.backward()
+        ws = torch.empty(N.loss_workspace_size(3, H, W), dtype=torch.uint8, device=dev)
+        sums = torch.zeros(2, device=dev)
+        grad = torch.full_like(a, float("nan")).detach()
+        up = torch.ones(1, device=dev)
+        ad = a.detach()
+        for y0, y1 in zip(cuts[:-1], cuts[1:]):
+            out2 = torch.empty(2, device=dev)
+            N.loss_forward_rows(ad, b, ws, out2, y0, y1)
+            sums += out2
+            piece = torch.zeros_like(ad)
+            N.loss_backward_rows(ad, b, 0.2, up, ws, piece, y0, y1)
+            assert float(piece[:, :y0].abs().sum()) == 0 and float(piece[:, y1:].abs().sum()) == 0
+            grad[:, y0:y1] = piece[:, y0:y1]
+        n = a.numel()
+        loss = 0.8 * sums[0] / n + 0.2 * (1 - sums[1] / n)
+        assert abs(float(loss) - float(full.detach())) < 2e-6, (H, W)
+        assert torch.allclose(grad, a.grad, rtol=1e-5, atol=1e-9), (H, W, float((grad - a.grad).abs().max()))
