@@ -465,6 +465,23 @@ def test_sharded_renderer_native_backend_world1():
         assert torch.equal(res[0][2], res[1][2])
         for a, b in zip(res[0][3], res[1][3]):
             assert torch.equal(a, b)
+        # the bench's N > 1 step: render + slab-local loss + backward over RCCL (device-tensor collectives incl. the
+        # deferred MAX and the 8-byte sum of the loss terms) against the single-GPU step
+        import loss_utils
+        gt = torch.rand(3, 200, 320, generator=torch.Generator().manual_seed(2)).to(DEV)
+        steps = []
+        for mode in ("plain", "sharded"):
+            model = GaussianParams(scene.to(DEV)).to(DEV)
+            if mode == "plain":
+                loss = loss_utils.training_loss(render(cam, model, Pipe(), bg)["render"], gt)
+            else:
+                sr = ShardedRenderer(dist, 1, 0)
+                loss = sr.training_loss(sr.render(cam, model, Pipe(), bg)["render"], gt)
+            loss.backward()
+            steps.append((float(loss.detach()), [p.grad.clone() for p in model.parameters()]))
+        assert abs(steps[0][0] - steps[1][0]) < 2e-6
+        for a, b in zip(steps[0][1], steps[1][1]):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-7 * float(a.abs().max()))
     finally:
         dist.destroy_process_group()
 
