@@ -49,6 +49,7 @@ def algorithmic_bytes(P, V, Re, N, Tn, K, M, Vlive, C=3):
         "reduce_rows": 36 * Re + 36 * P,                    # deterministic reduction (replaces atomic RMW)
         "geom_bwd": 4 * P + (99 + 12 * K) * Vlive + (40 + 12 * M) * P,   # K8 + K9
         "loss_fwd": 20 * C * N, "loss_bwd": 24 * C * N,
+        "zero_outputs": (104 + 12 * M) * P,                # early zero fill: screen-space (48 B) + parameter gradients
     }
 
 
@@ -179,7 +180,7 @@ def main():
     dom = max(prof, key=lambda k: prof[k][0])
     launches = max(prof[dom][1], 1)
     dom_ms = prof[dom][0] / launches                              # average duration of one launch
-    bytes_per_launch = alg[dom] * args.steps / launches
+    bytes_per_launch = alg.get(dom, 0) * args.steps / launches
     achieved = (bytes_per_launch / 1e9) / (dom_ms / 1e3)
     roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 5), traffic=_traffic_from_profiles(dom) if (args.workload == "cfg3" and world == 1) else None,
