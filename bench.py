@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="rehearsal on one GPU: run the N > 1 code path (RCCL process group, ShardedRenderer, slab-local loss) "
+                         "with world_size 1")
     ap.add_argument("--train-loop", type=int, default=0, metavar="ITERS",
                     help="also time ITERS iterations of the full training loop (Adam, densify every 100) on the workload")
     args = ap.parse_args()
@@ -73,10 +76,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import scene_synth as S
     from diff_gaussian_rasterization import _native as N
@@ -93,7 +100,7 @@ def main():
     gt = torch.rand(3, cfg["H"], cfg["W"], generator=torch.Generator().manual_seed(cfg["seed"] + 100)).to(dev)
     pipe = Pipe()
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         from diff_gaussian_rasterization.sharded import ShardedRenderer
         sharded = ShardedRenderer(dist, world, rank)
     else:
@@ -140,7 +147,7 @@ def main():
     # store (exp / sigmoid / normalize / cat and their backward) fused into the HIP kernels
     # (pipe.fused_activations -> GaussianRasterizer.forward_raw) instead of running as ~30 torch kernels
     fused = None
-    if world == 1:
+    if sharded is None:
         pipe.fused_activations = True
         for _ in range(max(args.warmup, 1)):
             step()
@@ -215,7 +222,7 @@ def main():
                                f"(SURVEY Appendix B seed {cfg['seed']}); step = render() + L1/D-SSIM loss + backward "
                                f"(train.py:79-108 window)",
                    "visible": V, "num_rendered": R, "instances_emitted": Re, "chunks_run": stats["chunks_run"],
-                   "parallelism": "single" if world == 1 else f"tile-row slabs x{world}"},
+                   "parallelism": "single" if sharded is None else f"tile-row slabs x{world}"},
         "raster_ms_per_step": round(raster_ms, 4), "profiled_ms_per_step": round(1e3 * elapsed_profiled / args.steps, 4),
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                     for k, v in per_kernel.items()},

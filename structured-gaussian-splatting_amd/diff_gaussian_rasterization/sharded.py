@@ -87,6 +87,11 @@ class NativeBackend:
         from . import rasterize_backward_geom
         return rasterize_backward_geom(frame, screen, needs, g0, g1, binned_ranks=binned_ranks)
 
+    def prepare_backward(self, frame, needs):
+        """Early zero fill of the backward's outputs (gsr_backward_prepare) while the stream waits for the all-gather."""
+        from . import prepare_backward
+        prepare_backward(frame, needs)
+
     def binned_prefix(self, frame):
         """(depth_order[P] as a device tensor, number of leading depth ranks that may own gradient rows)."""
         from . import _native as N
@@ -123,6 +128,39 @@ class _Comm:
         t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if self.gloo else device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
+
+    def read_later(self, scalar: torch.Tensor):
+        """A device integer scalar that the host will need later (the backward): copied to pinned memory behind whatever
+        produced it, with an event; the returned callable waits for that event only.  A blocking .item() in the backward
+        would drain the whole forward + loss from the stream."""
+        if scalar.device.type != "cuda":
+            v = int(scalar.item())
+            return lambda: v
+        host = torch.empty(1, dtype=torch.int64).pin_memory()
+        host.copy_(scalar.reshape(1).to(torch.int64), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(scalar.device))
+
+        def read():
+            ev.synchronize()
+            return int(host[0])
+        return read
+
+    def read_halves_later(self, halves: torch.Tensor):
+        """halves [world, 2] = (n >> 16, n & 0xFFFF) per rank as floats: one copy to pinned memory + an event now; the
+        returned callable waits for that event and returns max over ranks of n."""
+        if halves.device.type != "cuda":
+            v = int((halves[:, 0].to(torch.int64) * 65536 + halves[:, 1].to(torch.int64)).max().item())
+            return lambda: v
+        host = torch.empty(halves.shape, dtype=halves.dtype).pin_memory()
+        host.copy_(halves, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(halves.device))
+
+        def read():
+            ev.synchronize()
+            return max(int(h) * 65536 + int(l) for h, l in host.tolist())
+        return read
 
     def max_int_deferred(self, value: int, device):
         """MAX over ranks of a host integer, started now and read later: returns a callable.  On RCCL the reduced word
@@ -165,26 +203,36 @@ class _ShardedRasterize(torch.autograd.Function):
         slabs = shard.slabs(Gy)
         ty0, ty1 = slabs[comm.rank]
         rows_max = max(min(b * 16, H) - min(a * 16, H) for a, b in slabs)
-        # render own slab into a padded [3, rows_max, W] buffer positioned at image row 0 of the buffer
-        full = torch.zeros(3, H, W, dtype=means3D.dtype, device=means3D.device)
+        # render own slab straight into the full-size frame (rows of the other slabs arrive with the all-gather)
+        full = torch.empty(3, H, W, dtype=means3D.dtype, device=means3D.device)
         color, radii, frame = backend.forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                               rs, (ty0, ty1) if ty1 > ty0 else (Gy, Gy), full)
         y0, y1 = min(ty0 * 16, H), min(ty1 * 16, H)
-        mine = torch.zeros(1, 3, rows_max, W, dtype=full.dtype, device=full.device)
+        # all-gather payload per rank: its slab padded to rows_max rows, plus two trailing words that carry the length of
+        # its binned depth prefix (as 16-bit halves, exact in any float type) so that the MAX over ranks needs no
+        # collective of its own
+        n_words = 3 * rows_max * W
+        mine = torch.empty(1, n_words + 2, dtype=full.dtype, device=full.device)
         if y1 > y0:
-            mine[0, :, :y1 - y0] = full[:, y0:y1]
-        gathered = comm.all_gather(mine)                        # [world, 3, rows_max, W]
+            mine[0, :n_words].view(3, rows_max, W)[:, :y1 - y0] = full[:, y0:y1]
+        want_prefix = shard.backward_mode == "allreduce_screen" and any(ctx.needs_input_grad[:8])
+        order, n_mine = backend.binned_prefix(frame) if want_prefix else (None, 0)
+        mine[0, n_words].fill_(float(int(n_mine) >> 16))
+        mine[0, n_words + 1].fill_(float(int(n_mine) & 0xFFFF))
+        gathered = comm.all_gather(mine)                        # [world, 3 * rows_max * W + 2]
         for r, (a, b) in enumerate(slabs):
             a_px, b_px = min(a * 16, H), min(b * 16, H)
             if b_px > a_px and r != comm.rank:
-                full[:, a_px:b_px] = gathered[r, :, :b_px - a_px]
+                full[:, a_px:b_px] = gathered[r, :n_words].view(3, rows_max, W)[:, :b_px - a_px]
         ctx.frame, ctx.shard, ctx.rs = frame, shard, rs
         ctx.n_max = None
-        if shard.backward_mode == "allreduce_screen" and any(ctx.needs_input_grad[:8]):
-            # longest binned depth prefix over the ranks: sizes the backward's gradient exchange; started here so
-            # that the backward finds it on the host without a stream drain
-            order, n_mine = backend.binned_prefix(frame)
-            ctx.n_max = (order, comm.max_int_deferred(n_mine, means3D.device) if order is not None else None)
+        if want_prefix:
+            # longest binned depth prefix over the ranks: sizes the backward's gradient exchange; on its way to pinned
+            # host memory now, so that the backward finds it without a stream drain
+            ctx.n_max = (order, comm.read_halves_later(gathered[:, n_words:]) if order is not None else None)
+            hook = getattr(backend, "prepare_backward", None)       # the native provider zero-fills the backward's outputs now
+            if hook is not None:
+                hook(frame, tuple(ctx.needs_input_grad[:8]))
         ctx.shapes = (means2D.shape, opacities.shape)
         ctx.mark_non_differentiable(radii)
         return full, radii
@@ -210,7 +258,7 @@ class _ShardedRasterize(torch.autograd.Function):
             else:
                 screen = partial                                    # rows outside the prefix are zero on every rank
                 if n_max > 0:
-                    idx = order[:n_max].long()
+                    idx = order[:n_max] if order.dtype in (torch.int32, torch.int64) else order[:n_max].long()
                     screen[idx] = comm.all_reduce_sum(partial[idx].contiguous())       # in place: `partial` is not used again
             # (3) every rank runs the whole geometry backward: full parameter gradients, no further collective
             out = list(backend.backward_geom(frame, screen, needs, 0, P, n_max if order is not None else -1))
