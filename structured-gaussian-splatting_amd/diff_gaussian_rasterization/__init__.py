@@ -321,6 +321,80 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings)
 
 
+# ---- opt-in: fuse the reference's getters without touching the caller -------------------------------------------
+# With FUSE_GETTERS on (module attribute, or GSR_FUSE_GETTERS=1 in the environment) GaussianRasterizer.forward looks at
+# the autograd history of its arguments.  If they are exactly what the reference's GaussianModel getters produce from
+# leaf parameters — opacities = sigmoid(leaf), scales = exp(leaf), rotations = F.normalize(leaf),
+# shs = cat((leaf_dc, leaf_rest), 1), means3D a leaf (scene/gaussian_model.py:101-125) — the frame is rendered
+# from those leaves with the activations inside the kernels (forward_raw).  Pixels are the same; the gradients reach
+# the same leaves with the same values to fp32 rounding, but the ~15 torch kernels of the getters' backward (and the
+# 2 x 192 MB copies of cat's) never run.  Anything that does not match falls back to the plain path.  Not default:
+# hooks / retain_grad() on the intermediate activated tensors would not fire.
+import os as _os
+
+FUSE_GETTERS = _os.environ.get("GSR_FUSE_GETTERS", "0") not in ("", "0")
+
+
+def _leaf_of(fn, index=0):
+    """The leaf tensor behind input `index` of autograd node `fn`, or None."""
+    nxt = fn.next_functions
+    if index >= len(nxt) or nxt[index][0] is None or type(nxt[index][0]).__name__ != "AccumulateGrad":
+        return None
+    return nxt[index][0].variable
+
+
+def _unary_getter(t, node_name):
+    fn = t.grad_fn
+    if fn is None or type(fn).__name__ != node_name or len(fn.next_functions) != 1:
+        return None
+    leaf = _leaf_of(fn)
+    return leaf if leaf is not None and leaf.shape == t.shape and leaf.dtype == torch.float32 else None
+
+
+def _normalize_getter(t):
+    """leaf such that t = torch.nn.functional.normalize(leaf) (p = 2, dim = 1, eps = 1e-12), or None."""
+    fn = t.grad_fn
+    if fn is None or type(fn).__name__ != "DivBackward0" or len(fn.next_functions) != 2:
+        return None
+    leaf = _leaf_of(fn, 0)
+    node = fn.next_functions[1][0]
+    for name in ("ExpandBackward0", "ClampMinBackward0", "LinalgVectorNormBackward0"):
+        if node is None or type(node).__name__ != name:
+            return None
+        if name == "ClampMinBackward0" and abs(float(node._saved_min) - 1e-12) > 1e-18:
+            return None
+        if name == "LinalgVectorNormBackward0":
+            if float(node._saved_ord) != 2.0 or tuple(node._saved_dim) != (1,) or not node._saved_keepdim:
+                return None
+            if _leaf_of(node) is not leaf:
+                return None
+            break
+        node = node.next_functions[0][0] if len(node.next_functions) == 1 else None
+    return leaf if leaf is not None and leaf.shape == t.shape and leaf.dtype == torch.float32 else None
+
+
+def _match_getters(means3D, opacities, shs, scales, rotations):
+    """(xyz, f_dc, f_rest, opacity, scaling, rotation) leaves when the arguments are the reference getters' outputs."""
+    try:
+        if not (means3D.is_leaf and means3D.dtype == torch.float32 and means3D.is_cuda):
+            return None
+        op, sc, rot = _unary_getter(opacities, "SigmoidBackward0"), _unary_getter(scales, "ExpBackward0"), _normalize_getter(rotations)
+        fn = shs.grad_fn
+        if op is None or sc is None or rot is None or fn is None or type(fn).__name__ != "CatBackward0":
+            return None
+        if int(fn._saved_dim) != 1 or len(fn.next_functions) != 2:
+            return None
+        dc, rest = _leaf_of(fn, 0), _leaf_of(fn, 1)
+        P = means3D.shape[0]
+        if dc is None or rest is None or tuple(dc.shape) != (P, 1, 3) or rest.dim() != 3 or rest.shape[0] != P or rest.shape[2] != 3:
+            return None
+        if dc.dtype != torch.float32 or rest.dtype != torch.float32 or rest.shape[1] + 1 != shs.shape[1] or rest.shape[1] == 0:
+            return None
+        return means3D, dc, rest, op, sc, rot
+    except (AttributeError, RuntimeError, TypeError):
+        return None
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings: GaussianRasterizationSettings):
         super().__init__()
@@ -354,6 +428,11 @@ class GaussianRasterizer(nn.Module):
         cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
         rs = rs._replace(sh_degree=int(rs.sh_degree), image_height=int(rs.image_height),
                          image_width=int(rs.image_width))
+        if FUSE_GETTERS and torch.is_grad_enabled() and not rs.debug and shs.numel() and scales.numel() and rotations.numel():
+            leaves = _match_getters(means3D, opacities, shs, scales, rotations)
+            if leaves is not None:
+                xyz, dc, rest, op, sc, rot = leaves
+                return _RasterizeGaussiansRaw.apply(xyz, means2D, dc, rest, op, sc, rot, rs)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, rs)
 

@@ -891,3 +891,47 @@ def test_bench_line_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
     assert r["traffic"] is None                      # PMC traffic is only attached to the run it was measured on (cfg3)
     assert d["cpu_baseline"] is None                 # --no-cpu-baseline
+
+
+def test_getter_fusion_is_transparent():
+    """FUSE_GETTERS (opt-in): render() exactly as the reference writes it — getters, standard forward() — with the flag on
+    reaches the raw-parameter kernels through the autograd-history match: same image, same gradients on the leaves;
+    arguments that are not the getters' outputs (a scaled opacity here) take the plain path."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_params import GaussianParams, Pipe
+    from gaussian_renderer import render
+    W, H = 320, 208
+    scene = S.make_scene(20_000, W, H, 3, 23, scale_lo=0.005, scale_hi=0.06).to(DEV)
+    cam = S.make_camera(W, H).to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    gimg = S.make_grad_image(W, H, 6).to(DEV)
+    seen = []
+    orig = dgr._RasterizeGaussiansRaw.apply
+    results = []
+    try:
+        for on in (False, True):
+            dgr.FUSE_GETTERS = on
+            dgr._RasterizeGaussiansRaw.apply = staticmethod(lambda *a, **k: (seen.append(on), orig(*a, **k))[1])
+            model = GaussianParams(scene).to(DEV)
+            out = render(cam, model, Pipe(), bg)
+            out["render"].backward(gimg)
+            torch.cuda.synchronize()
+            results.append((out["render"].detach(), {n: p.grad.clone() for n, p in model.named_parameters()},
+                            out["viewspace_points"].grad.clone()))
+        assert seen == [True]                                   # the raw path ran exactly once: with the flag on
+        (ia, ga, va), (ib, gb, vb) = results
+        derr = (ia - ib).abs().amax(0)
+        assert float((derr > 2e-5).float().mean()) <= 1e-4 and float(derr.max()) <= 8e-3
+        for n in ga:
+            assert float((ga[n] - gb[n]).norm() / ga[n].norm()) <= 1e-4, n
+        assert float((va - vb).norm() / va.norm()) <= 1e-4
+        # a look-alike: opacity scaled after the sigmoid -> no match, plain path, still correct
+        seen.clear()
+        model = GaussianParams(scene).to(DEV)
+        rs = _settings(raster_kwargs(scene.to("cpu"), S.make_camera(W, H)))
+        color, _ = dgr.GaussianRasterizer(rs)(means3D=model.get_xyz, means2D=torch.zeros(scene.P, 3, device=DEV), shs=model.get_features,
+                                              opacities=model.get_opacity * 0.5, scales=model.get_scaling, rotations=model.get_rotation)
+        assert seen == [] and torch.isfinite(color).all()
+    finally:
+        dgr.FUSE_GETTERS = False
+        dgr._RasterizeGaussiansRaw.apply = orig

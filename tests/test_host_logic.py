@@ -48,3 +48,25 @@ def test_gaussian_params_getters_and_defaults():
     for k in ("convert_SHs_python", "compute_cov3D_python", "debug"):
         assert getattr(Pipe, k) == params["pipeline"][k]
     assert params["optimization"]["lambda_dssim"] == 0.2
+
+
+def test_getter_fusion_matcher_accepts_only_the_reference_getters():
+    """diff_gaussian_rasterization._match_getters (opt-in FUSE_GETTERS): the autograd-history patterns of the reference's
+    GaussianModel getters are recognised exactly; look-alikes are refused (then the plain path runs)."""
+    import torch
+    import torch.nn.functional as F
+    import diff_gaussian_rasterization as d
+    x = torch.randn(7, 4, requires_grad=True)
+    s = torch.randn(7, 3, requires_grad=True)
+    o = torch.randn(7, 1, requires_grad=True)
+    assert d._normalize_getter(F.normalize(x)) is x
+    assert d._normalize_getter(x / x.norm(dim=1, keepdim=True)) is None              # no clamp_min: not F.normalize
+    assert d._normalize_getter(F.normalize(x, dim=0)) is None and d._normalize_getter(F.normalize(x, eps=1e-6)) is None
+    assert d._normalize_getter(F.normalize(x * 1.0)) is None                           # not a leaf behind it
+    assert d._unary_getter(torch.exp(s), "ExpBackward0") is s and d._unary_getter(torch.sigmoid(o), "SigmoidBackward0") is o
+    assert d._unary_getter(torch.exp(s) * 2.0, "ExpBackward0") is None and d._unary_getter(torch.exp(s.detach()), "ExpBackward0") is None
+    assert d._unary_getter(torch.sigmoid(o)[:5], "SigmoidBackward0") is None
+    # the whole matcher needs device tensors for means3D; on the CPU it declines
+    dc, rest = torch.randn(7, 1, 3, requires_grad=True), torch.randn(7, 15, 3, requires_grad=True)
+    m = torch.randn(7, 3, requires_grad=True)
+    assert d._match_getters(m, torch.sigmoid(o), torch.cat((dc, rest), 1), torch.exp(s), F.normalize(x)) is None
