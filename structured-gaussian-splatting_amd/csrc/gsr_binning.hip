@@ -29,7 +29,8 @@ namespace gsr {
 
 constexpr uint32_t kMinFirstChunk = 1u << 20;    // instances in the first depth chunk (at least)
 constexpr int kFirstChunkDiv = 8;                // first chunk <= R / 8 ...
-constexpr int kFirstChunkPerTile = 384;          // ... and ~384 instances per tile: tiles saturate after a few hundred splats
+constexpr int kFirstChunkPerTile = 288;          // ... and ~288 upper-bound instances per tile: the synthetic scenes' tiles all close
+                                                 // within 210-230 (cfg3 / cfg5 sweep: 208 needs a second chunk, 384 emits 35 % more)
 constexpr int kChunkGrowthLog2 = 2;              // then x4 per chunk
 
 GeomWS carve_geom(void *base, int P)
@@ -125,13 +126,13 @@ __device__ __forceinline__ uint32_t wave_lower_bound(uint32_t n, Pred pred)   //
     return lo;
 }
 
-__global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int P, int n_tiles, const uint32_t *__restrict__ sorted_keys,
+__global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int P, int n_tiles, int per_tile, const uint32_t *__restrict__ sorted_keys,
                                                                             const uint32_t *__restrict__ offs_full, Ctrl *ctrl)
 {
     __shared__ uint32_t sh_V, sh_end[GSR_MAX_CHUNKS];
     const uint32_t R = ctrl->R_total;
     const int w = threadIdx.x >> 6;
-    uint32_t first = (uint32_t)kFirstChunkPerTile * (uint32_t)n_tiles;
+    uint32_t first = (uint32_t)per_tile * (uint32_t)n_tiles;
     if (first > R / (uint32_t)kFirstChunkDiv) first = R / (uint32_t)kFirstChunkDiv;
     if (first < kMinFirstChunk) first = kMinFirstChunk;
     if (w == 0) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int 
 int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 {
     ProfileScope prof("chunk_plan", s);
-    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(kWave * (GSR_MAX_CHUNKS + 1)), 0, s, f.P, (f.ty1 - f.ty0) * f.Gx, ws.sort_keys[0], ws.offs_full, ws.ctrl);
+    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(kWave * (GSR_MAX_CHUNKS + 1)), 0, s, f.P, (f.ty1 - f.ty0) * f.Gx, kFirstChunkPerTile, ws.sort_keys[0], ws.offs_full, ws.ctrl);
     GSR_LAUNCH_CHECK("chunk_plan", debug, s);
     return GSR_OK;
 }
