@@ -129,26 +129,10 @@ class _Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return int(t.item())
 
-    def read_later(self, scalar: torch.Tensor):
-        """A device integer scalar that the host will need later (the backward): copied to pinned memory behind whatever
-        produced it, with an event; the returned callable waits for that event only.  A blocking .item() in the backward
-        would drain the whole forward + loss from the stream."""
-        if scalar.device.type != "cuda":
-            v = int(scalar.item())
-            return lambda: v
-        host = torch.empty(1, dtype=torch.int64).pin_memory()
-        host.copy_(scalar.reshape(1).to(torch.int64), non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(scalar.device))
-
-        def read():
-            ev.synchronize()
-            return int(host[0])
-        return read
-
     def read_halves_later(self, halves: torch.Tensor):
         """halves [world, 2] = (n >> 16, n & 0xFFFF) per rank as floats: one copy to pinned memory + an event now; the
-        returned callable waits for that event and returns max over ranks of n."""
+        returned callable waits for that event only and returns max over ranks of n.  (A blocking .item() in the
+        backward would drain the whole forward + loss from the stream.)"""
         if halves.device.type != "cuda":
             v = int((halves[:, 0].to(torch.int64) * 65536 + halves[:, 1].to(torch.int64)).max().item())
             return lambda: v
@@ -160,25 +144,6 @@ class _Comm:
         def read():
             ev.synchronize()
             return max(int(h) * 65536 + int(l) for h, l in host.tolist())
-        return read
-
-    def max_int_deferred(self, value: int, device):
-        """MAX over ranks of a host integer, started now and read later: returns a callable.  On RCCL the reduced word
-        is copied to pinned host memory behind the collective and an event is recorded, so reading it in the backward
-        does not make the host wait for the stream (a blocking .item() there drains the whole forward + loss)."""
-        if self.gloo:
-            v = self.max_int(value, device)
-            return lambda: v
-        t = torch.tensor([int(value)], dtype=torch.int64).pin_memory().to(device, non_blocking=True)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        host = torch.empty(1, dtype=torch.int64).pin_memory()
-        host.copy_(t, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(device))
-
-        def read():
-            ev.synchronize()
-            return int(host[0])
         return read
 
     def reduce_scatter_sum(self, full: torch.Tensor) -> torch.Tensor:
