@@ -213,6 +213,11 @@ def main():
                     avg_launch_ms=round(dom_ms, 4), algorithmic_bytes_per_launch=int(bytes_per_launch),
                     step_algorithmic_bytes=int(sum(alg.values())),
                     step_frac=round(sum(alg.values()) / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 5),
+                    # context only: SURVEY 8d's whole-step total evaluated as the REFERENCE's algorithm would move it, i.e.
+                    # with all R = num_rendered duplicates (this design bins `instances_emitted` of them), over the same time
+                    reference_formula_step_bytes=int((144 + 12 * M) * P + (182 + 24 * K) * V + 160 * R + 40 * Npix + 8 * Tn),
+                    reference_formula_step_frac=round(((144 + 12 * M) * P + (182 + 24 * K) * V + 160 * R + 40 * Npix + 8 * Tn)
+                                                      / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 5),
                     note="blend kernels are VALU-bound (SURVEY 8d caveat): secondary rate = "
                          f"{pairs / 1e9 / (per_kernel.get('render_bwd', {}).get('ms_per_step', 0) / 1e3 + 1e-12):.1f} "
                          "G (pixel,splat) pairs/s in render_bwd")
