@@ -150,9 +150,14 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
         __syncthreads();
         // Strip pairs (rows 0-7 and 8-15 of the tile) whose 128 pixels have all taken the cut-off are skipped for
         // the whole batch: a wave-uniform flag per pair, evaluated once per 64 splats.
-        const bool pair_live0 = __ballot((Tl[0] != 0.f) || (Tl[1] != 0.f)) != 0ull;
-        const bool pair_live1 = __ballot((Tl[2] != 0.f) || (Tl[3] != 0.f)) != 0ull;
+        bool pair_live0 = __ballot((Tl[0] != 0.f) || (Tl[1] != 0.f)) != 0ull;
+        bool pair_live1 = __ballot((Tl[2] != 0.f) || (Tl[3] != 0.f)) != 0ull;
         for (int j = 0; j < n; ++j) {
+            if ((j & 7) == 0 && j) {            // every 8 splats: a tile that saturates mid-batch stops there, not 30 splats later
+                pair_live0 = pair_live0 && __ballot((Tl[0] != 0.f) || (Tl[1] != 0.f)) != 0ull;
+                pair_live1 = pair_live1 && __ballot((Tl[2] != 0.f) || (Tl[3] != 0.f)) != 0ull;
+                if (!pair_live0 && !pair_live1) break;
+            }
             const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
             const float cb = sh_rec[3 * j + 2].x;
             const float dx = a.x - fx;
