@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 6
+#define GSR_VERSION 7
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -130,9 +130,10 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
 /* Stage 2 of `_C.rasterize_gaussians`: per depth chunk — emit (tile, instance) pairs into open tiles,
  * stable radix sort by tile, tile ranges, per-tile front-to-back blend continuing each pixel's state.
  * Stops as soon as no tile is open (one 4-byte readback per chunk).  Updates plan_host->chunks_run /
- * instances_emitted.  Rows of out_color outside the slab are left untouched. */
-int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *geom_ws, void *binning_ws,
-                       void *image_ws, gsr_frame_plan *plan_host, float *out_color, void *stream);
+ * instances_emitted.  Rows of out_color outside the slab are left untouched.  `g` = the same tensors as in stage 1:
+ * SH colours (A.6) are evaluated HERE, per chunk, only for the Gaussians of the chunks that get binned. */
+int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws,
+                       void *binning_ws, void *image_ws, gsr_frame_plan *plan_host, float *out_color, void *stream);
 
 /* Size of the backward-only scratch: one 48-byte gradient row per instance the forward EMITTED
  * (plan_host->instances_emitted, a few per cent of num_rendered; the emission bound of the chunks that ran

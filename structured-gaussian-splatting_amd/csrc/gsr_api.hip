@@ -225,11 +225,12 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     return GSR_OK;
 }
 
-int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *geom_ws, void *binning_ws, void *image_ws,
-                       gsr_frame_plan *plan, float *out_color, void *stream)
+int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws, void *binning_ws,
+                       void *image_ws, gsr_frame_plan *plan, float *out_color, void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
+    if ((rc = validate_inputs(desc, cam, g))) return rc;
     if (!cam || !cam->bg || !image_ws || !out_color || !plan || plan->num_rendered < 0 ||
         (desc->P > 0 && !geom_ws) || (plan->num_rendered > 0 && !binning_ws)) {
         set_error("gsr_forward_render: NULL argument");
@@ -265,6 +266,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, void *
                                        dbg, s)))
             return rc;
         cand_before += (uint64_t)plan->chunk_instances_max[c];
+        if ((rc = launch_chunk_colors(f, *cam, *g, r0, r1, gw, dbg, s))) return rc;      // A.6 for this chunk's Gaussians only
         if ((rc = launch_render_fwd(f, *cam, c, last, gw, bw, iw, out_color, dbg, s))) return rc;
         plan->chunks_run = c + 1;
         plan->instances_emitted = -1;                 // the last chunk's count stays on the device

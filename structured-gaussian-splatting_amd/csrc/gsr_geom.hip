@@ -68,7 +68,7 @@ __device__ __forceinline__ void load_gaussian(int i, int M, const float *__restr
     }
 }
 
-template <int DEG, bool RAW>
+template <int DEG, bool RAW, bool LAZY>
 __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float *__restrict__ view,
                                                            const float *__restrict__ proj, const float *__restrict__ campos,
                                                            const float *__restrict__ means, const float *__restrict__ scales,
@@ -92,9 +92,11 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
     // prefiltered = "the caller guarantees every point passes the frustum test" (the upstream kernel traps when one
     // does not); here the frame is refused with GSR_ERR_PREFILTERED after the plan readback
     if (prefilter_flag && !near_ok) *prefilter_flag = 1u;
-    load_gaussian<DEG, RAW>(i, f.M, means, scales, rots, covpre, opac, shs, shs_rest, near_ok, in);
+    // LAZY: SH colours are evaluated per depth chunk (k_chunk_colors), only for the chunks that get binned; this kernel then
+    // reads no coefficient at all (two thirds of its bytes at degree 3)
+    load_gaussian<DEG, RAW>(i, f.M, means, scales, rots, covpre, opac, shs, shs_rest, near_ok && !LAZY, in);
     PreOut o;
-    preprocess_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.opacity, in.sh(),
+    preprocess_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.opacity, LAZY ? nullptr : in.sh(),
                         (!RAW && colpre) ? colpre + 3 * (size_t)i : nullptr, o);
     radii[i] = o.radius;
     tiles[i] = o.tiles;
@@ -120,28 +122,83 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
         GSR_HIP_CHECK(hipMemsetAsync(prefilter_flag, 0, 4, s));
     }
     ProfileScope prof("preprocess", s);
-#define GSR_PRE(DEG, RAW)                                                                                           \
-    hipLaunchKernelGGL((k_preprocess<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
+#define GSR_PRE(DEG, RAW, LAZY)                                                                                     \
+    hipLaunchKernelGGL((k_preprocess<DEG, RAW, LAZY>), dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
                        cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs, g.shs_rest,   \
                        g.colors_precomp, ws.records, ws.tiles_touched, ws.clamped, radii, ws.sort_keys[0],              \
                        ws.sort_vals[0], prefilter_flag)
-    if (g.raw) {
-        switch (f.D) {
-            case 0: GSR_PRE(0, true); break;
-            case 1: GSR_PRE(1, true); break;
-            case 2: GSR_PRE(2, true); break;
-            default: GSR_PRE(3, true); break;
-        }
+    if (g.shs) {                  // colours from SH: lazily, per binned chunk
+        if (g.raw) GSR_PRE(0, true, true);
+        else GSR_PRE(0, false, true);
     } else {
-        switch (g.shs ? f.D : 0) {
-            case 0: GSR_PRE(0, false); break;
-            case 1: GSR_PRE(1, false); break;
-            case 2: GSR_PRE(2, false); break;
-            default: GSR_PRE(3, false); break;
-        }
+        GSR_PRE(0, false, false);  // precomputed colours are copied into the record here
     }
 #undef GSR_PRE
     GSR_LAUNCH_CHECK("preprocess", debug, s);
+    return GSR_OK;
+}
+
+// ---- A.6, lazily: SH colour (+ clamp flags) of the Gaussians of depth ranks [r0, r1) — one binned chunk — patched into
+// their splat records right before the chunk is blended.  On a depth-complex frame that is a few thousand Gaussians
+// instead of all the visible ones.
+template <int DEG, bool RAW>
+__global__ __launch_bounds__(kGeomBlock) void k_chunk_colors(FrameK f, int r0, int r1, const uint32_t *__restrict__ order,
+                                                             const float *__restrict__ campos, const float *__restrict__ means,
+                                                             const float *__restrict__ shs, const float *__restrict__ shs_rest,
+                                                             float4 *__restrict__ records, uint8_t *__restrict__ clamped)
+{
+    const int r = r0 + blockIdx.x * kGeomBlock + threadIdx.x;
+    if (r >= r1) return;
+    const int i = (int)order[r];
+    const float cp[3] = {campos[0], campos[1], campos[2]};
+    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    float shl[3 * K];
+    if constexpr (RAW) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) shl[ch] = shs[3 * (size_t)i + ch];
+        const float *rest = shs_rest + (size_t)i * (f.M - 1) * 3;
+#pragma unroll
+        for (int k = 3; k < 3 * K; ++k) shl[k] = rest[k - 3];
+    } else {
+        const float *src = shs + (size_t)i * f.M * 3;
+#pragma unroll
+        for (int k = 0; k < 3 * K; ++k) shl[k] = src[k];
+    }
+    float rgb[3];
+    unsigned cl;
+    sh_color_one<DEG>(f, cp, p, shl, rgb, cl);
+    float *rec = reinterpret_cast<float *>(records + 3 * (size_t)i);
+    rec[6] = rgb[0]; rec[7] = rgb[1]; rec[8] = rgb[2];          // record = {x, y, qA, qB | qC, lop, r, g | b, depth, rect, rect}
+    clamped[i] = (uint8_t)cl;
+}
+
+int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, GeomWS &ws, bool debug,
+                        hipStream_t s)
+{
+    if (!g.shs || r1 <= r0) return GSR_OK;           // precomputed colours went into the records in the preprocess
+    ProfileScope prof("chunk_colors", s);
+    const int grid = (r1 - r0 + kGeomBlock - 1) / kGeomBlock;
+#define GSR_CC(DEG, RAW)                                                                                             \
+    hipLaunchKernelGGL((k_chunk_colors<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, r0, r1, ws.order, cam.campos,     \
+                       g.means3D, g.shs, g.shs_rest, ws.records, ws.clamped)
+    if (g.raw) {
+        switch (f.D) {
+            case 0: GSR_CC(0, true); break;
+            case 1: GSR_CC(1, true); break;
+            case 2: GSR_CC(2, true); break;
+            default: GSR_CC(3, true); break;
+        }
+    } else {
+        switch (f.D) {
+            case 0: GSR_CC(0, false); break;
+            case 1: GSR_CC(1, false); break;
+            case 2: GSR_CC(2, false); break;
+            default: GSR_CC(3, false); break;
+        }
+    }
+#undef GSR_CC
+    GSR_LAUNCH_CHECK("chunk_colors", debug, s);
     return GSR_OK;
 }
 

@@ -258,8 +258,37 @@ struct PreOut {
     Splat s;
 };
 
-// ---- A.1-A.6 for one Gaussian.  `sh` points at this Gaussian's [M,3] coefficients (or null),
-// `colpre` at its precomputed colour (or null), `covpre` at its precomputed covariance (or null).
+// ---- A.6: colour of one Gaussian from its [K,3] SH coefficients (+0.5, clamp at 0; bit c of `clamped` = channel c
+// clamped).  Its own function because the forward evaluates it LAZILY: only for the depth chunks that are binned.
+template <int DEG = -1>
+GSR_HD void sh_color_one(const FrameK &f, const float *campos, const float p[3], const float *sh, float rgb[3], unsigned &clamped)
+{
+    float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
+    const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+    float bas[16];
+    const int D = DEG >= 0 ? DEG : f.D;          // DEG >= 0: compile-time degree, loops unroll
+    sh_basis<false>(D, dx, dy, dz, bas, nullptr, nullptr, nullptr);
+    const int K = (D + 1) * (D + 1);
+    clamped = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int ch = 0; ch < 3; ++ch) {
+        float acc = 0.f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int k = 0; k < K; ++k) acc += bas[k] * sh[3 * k + ch];
+        acc += (float)GSR_SH_OFFSET;
+        if (acc < 0.f) { clamped |= 1u << ch; acc = 0.f; }
+        rgb[ch] = acc;
+    }
+}
+
+// ---- A.1-A.6 for one Gaussian.  `sh` points at this Gaussian's [M,3] coefficients (or null: then, without a
+// precomputed colour, the colour is left at 0 for a later sh_color_one), `colpre` at its precomputed colour (or
+// null), `covpre` at its precomputed covariance (or null).
 template <int DEG = -1>
 GSR_HD void preprocess_one(const FrameK &f, const float *V, const float *PV, const float *campos,
                            const float p[3], const float *scale, const float *quat, const float *covpre,
@@ -297,30 +326,9 @@ GSR_HD void preprocess_one(const FrameK &f, const float *V, const float *PV, con
     TileRect r = tile_rect(px, py, my_radius, f);
     if ((r.x1 - r.x0) * (r.y1 - r.y0) == 0) return;
 
-    float rgb[3];
+    float rgb[3] = {0.f, 0.f, 0.f};
     if (colpre) { rgb[0] = colpre[0]; rgb[1] = colpre[1]; rgb[2] = colpre[2]; }
-    else {
-        float dx = p[0] - campos[0], dy = p[1] - campos[1], dz = p[2] - campos[2];
-        const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-        dx *= inv; dy *= inv; dz *= inv;
-        float bas[16];
-        const int D = DEG >= 0 ? DEG : f.D;          // DEG >= 0: compile-time degree, loops unroll
-        sh_basis<false>(D, dx, dy, dz, bas, nullptr, nullptr, nullptr);
-        const int K = (D + 1) * (D + 1);
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int ch = 0; ch < 3; ++ch) {
-            float acc = 0.f;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int k = 0; k < K; ++k) acc += bas[k] * sh[3 * k + ch];
-            acc += (float)GSR_SH_OFFSET;
-            if (acc < 0.f) { o.clamped |= 1u << ch; acc = 0.f; }
-            rgb[ch] = acc;
-        }
-    }
+    else if (sh) sh_color_one<DEG>(f, campos, p, sh, rgb, o.clamped);
     o.radius = (int)my_radius;
     o.s.x = px; o.s.y = py;
     o.s.cA = (-0.5f * kLog2e) * (e.c * det_inv); o.s.cB = -kLog2e * (-e.b * det_inv); o.s.cC = (-0.5f * kLog2e) * (e.a * det_inv);

@@ -138,7 +138,7 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
         if len(_binning_guess) > 64:
             _binning_guess.pop(next(iter(_binning_guess)))
         fr.binning_ws = binning
-        N.forward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, color, device)
+        N.forward_render(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, color, device)
     return color, fr.radii, fr
 
 

@@ -142,8 +142,8 @@ def forward_preprocess(desc, cam: Camera, g: Gaussians, geom_ws, radii, device, 
     return plan
 
 
-def forward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, plan: FramePlan, out_color, device):
-    _check(load().gsr_forward_render(C.byref(desc), C.byref(cam), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws),
+def forward_render(desc, cam: Camera, g: Gaussians, geom_ws, binning_ws, image_ws, plan: FramePlan, out_color, device):
+    _check(load().gsr_forward_render(C.byref(desc), C.byref(cam), C.byref(g), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws),
                                      C.byref(plan), _ptr(out_color), _stream(device)), "gsr_forward_render")
 
 
