@@ -74,10 +74,11 @@ def gaussian_shard(P: int, world: int, rank: int) -> Tuple[int, int, int]:
 class NativeBackend:
     """Compute provider = libgsrast.so through the drop-in package (the product path)."""
 
-    def forward(self, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, tile_rows, out_color):
+    def forward(self, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, tile_rows, out_color,
+                sh_rest=None, raw=False):
         from . import rasterize_forward
         return rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs,
-                                 tile_rows=tile_rows, out_color=out_color)
+                                 tile_rows=tile_rows, out_color=out_color, sh_rest=sh_rest, raw=raw)
 
     def backward_screen(self, frame, grad_color):
         from . import rasterize_backward_screen
@@ -161,8 +162,12 @@ class _Comm:
 
 class _ShardedRasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, shard):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, shard, sh_rest=None):
+        # sh_rest given = raw-parameter mode (SURVEY a14 fused): sh is _features_dc, sh_rest _features_rest, opacities /
+        # scales / rotations the raw parameters; the activations run inside the kernels on every rank
         comm, backend = shard.comm, shard.backend
+        raw = sh_rest is not None
+        ctx.raw = raw
         H, W = int(rs.image_height), int(rs.image_width)
         Gy = (H + 15) // 16
         slabs = shard.slabs(Gy)
@@ -170,8 +175,13 @@ class _ShardedRasterize(torch.autograd.Function):
         rows_max = max(min(b * 16, H) - min(a * 16, H) for a, b in slabs)
         # render own slab straight into the full-size frame (rows of the other slabs arrive with the all-gather)
         full = torch.empty(3, H, W, dtype=means3D.dtype, device=means3D.device)
-        color, radii, frame = backend.forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                              rs, (ty0, ty1) if ty1 > ty0 else (Gy, Gy), full)
+        slab = (ty0, ty1) if ty1 > ty0 else (Gy, Gy)
+        if raw:
+            color, radii, frame = backend.forward(means3D, sh, None, opacities, scales, rotations, None, rs, slab, full,
+                                                  sh_rest=sh_rest, raw=True)
+        else:
+            color, radii, frame = backend.forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                                  rs, slab, full)
         y0, y1 = min(ty0 * 16, H), min(ty1 * 16, H)
         # all-gather payload per rank: its slab padded to rows_max rows, plus two trailing words that carry the length of
         # its binned depth prefix (as 16-bit halves, exact in any float type) so that the MAX over ranks needs no
@@ -180,7 +190,9 @@ class _ShardedRasterize(torch.autograd.Function):
         mine = torch.empty(1, n_words + 2, dtype=full.dtype, device=full.device)
         if y1 > y0:
             mine[0, :n_words].view(3, rows_max, W)[:, :y1 - y0] = full[:, y0:y1]
-        want_prefix = shard.backward_mode == "allreduce_screen" and any(ctx.needs_input_grad[:8])
+        needs = tuple(ctx.needs_input_grad[:8]) + ((bool(ctx.needs_input_grad[10]),) if raw else ())
+        ctx.needs = needs
+        want_prefix = shard.backward_mode == "allreduce_screen" and any(needs)
         order, n_mine = backend.binned_prefix(frame) if want_prefix else (None, 0)
         mine[0, n_words].fill_(float(int(n_mine) >> 16))
         mine[0, n_words + 1].fill_(float(int(n_mine) & 0xFFFF))
@@ -197,7 +209,7 @@ class _ShardedRasterize(torch.autograd.Function):
             ctx.n_max = (order, comm.read_halves_later(gathered[:, n_words:]) if order is not None else None)
             hook = getattr(backend, "prepare_backward", None)       # the native provider zero-fills the backward's outputs now
             if hook is not None:
-                hook(frame, tuple(ctx.needs_input_grad[:8]))
+                hook(frame, needs)
         ctx.shapes = (means2D.shape, opacities.shape)
         ctx.mark_non_differentiable(radii)
         return full, radii
@@ -207,7 +219,7 @@ class _ShardedRasterize(torch.autograd.Function):
         frame, shard = ctx.frame, ctx.shard
         comm, backend = shard.comm, shard.backend
         P = frame.desc.P if hasattr(frame, "desc") else frame.P
-        needs = tuple(ctx.needs_input_grad[:8])
+        needs = ctx.needs
         # (1) my slab's contribution to every Gaussian's screen-space gradient
         partial = backend.backward_screen(frame, grad_color)                       # [P, 12]
         if shard.backward_mode == "allreduce_screen":
@@ -247,13 +259,14 @@ class _ShardedRasterize(torch.autograd.Function):
                 if g1 > g0:
                     blk[:g1 - g0] = g[g0:g1]
                 out.append(comm.all_gather(blk)[:P])
-        g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov = out
+        g_rest = out[8] if ctx.raw else None
+        g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov = out[:8]
         if g_op is not None:
             g_op = g_op.reshape(ctx.shapes[1])
         if g_means2D is not None:
             g_means2D = g_means2D.reshape(ctx.shapes[0])
         ctx.frame = None
-        return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None, None
+        return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None, None, g_rest
 
 
 class ShardedRenderer:
@@ -316,6 +329,14 @@ class ShardedRenderer:
             scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
             projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
             campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+        if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.compute_cov3D_python
+                and not getattr(pipe, "convert_SHs_python", False) and hasattr(pc, "_features_rest") and pc._features_rest.numel()
+                and isinstance(self.backend, NativeBackend)):
+            rs = rs._replace(sh_degree=int(rs.sh_degree))
+            e = torch.empty(0, dtype=torch.float32, device=xyz.device)
+            image, radii = _ShardedRasterize.apply(pc._xyz, screenspace_points, pc._features_dc, e, pc._opacity, pc._scaling,
+                                                   pc._rotation, e, rs, self, pc._features_rest)
+            return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
         scales = rotations = cov = None
         if pipe.compute_cov3D_python:
             cov = pc.get_covariance(scaling_modifier)

@@ -33,14 +33,16 @@ def _render(rank, world, mode):
     bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
     gt = torch.rand(3, 304, 400, generator=torch.Generator().manual_seed(77)).to(dev)
     loss_value = None
+    pipe = Pipe()
+    pipe.fused_activations = mode == "fused"          # raw parameters into the kernels, on one GPU and on the ranks alike
     if world == 1:
-        out = render(cam, model, Pipe(), bg)
+        out = render(cam, model, pipe, bg)
         if mode == "loss":
             loss = training_loss(out["render"], gt)
     else:
         from diff_gaussian_rasterization.sharded import ShardedRenderer
-        sr = ShardedRenderer(dist, world, rank, backward_mode="allreduce_screen" if mode == "loss" else mode)
-        out = sr.render(cam, model, Pipe(), bg)
+        sr = ShardedRenderer(dist, world, rank, backward_mode="allreduce_screen" if mode in ("loss", "fused") else mode)
+        out = sr.render(cam, model, pipe, bg)
         if mode == "loss":
             loss = sr.training_loss(out["render"], gt)
     if mode == "loss":
@@ -66,7 +68,8 @@ def _worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "allreduce_screen"), (3, "allreduce_screen"), (2, "reduce_scatter"), (3, "loss")])
+@pytest.mark.parametrize("world,mode", [(2, "allreduce_screen"), (3, "allreduce_screen"), (2, "reduce_scatter"), (3, "loss"),
+                                        (2, "fused")])
 def test_native_slabs_in_separate_processes_equal_single_render(world, mode):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
