@@ -93,6 +93,14 @@ class NativeBackend:
         from . import prepare_backward
         prepare_backward(frame, needs)
 
+    def row_work(self, frame, Gx, Gy):
+        """[Gy] float tensor: instances this frame binned per 16-px tile row (zero outside its slab) — the slab
+        balancer's measure of work."""
+        from . import _native as N
+        v = N.debug_views(frame.desc, frame.geom_ws, frame.binning_ws, frame.image_ws, frame.plan)
+        rng = v["ranges"][:max(int(frame.plan.chunks_run), 1)].long()             # [chunks, Tn, 2]
+        return (rng[..., 1] - rng[..., 0]).sum(0).view(Gy, Gx).sum(1).to(torch.float32)
+
     def binned_prefix(self, frame):
         """(depth_order[P] as a device tensor, number of leading depth ranks that may own gradient rows)."""
         from . import _native as N
@@ -170,6 +178,9 @@ class _ShardedRasterize(torch.autograd.Function):
         ctx.raw = raw
         H, W = int(rs.image_height), int(rs.image_width)
         Gy = (H + 15) // 16
+        # slab balancer: adopts weights measured on an earlier frame BEFORE this frame's slabs are cut (so that
+        # pixel_rows() / training_loss() after this render see the same slabs), and says whether this frame measures
+        balance = shard.balance_now(Gy) and hasattr(backend, "row_work")
         slabs = shard.slabs(Gy)
         ty0, ty1 = slabs[comm.rank]
         rows_max = max(min(b * 16, H) - min(a * 16, H) for a, b in slabs)
@@ -187,7 +198,7 @@ class _ShardedRasterize(torch.autograd.Function):
         # its binned depth prefix (as 16-bit halves, exact in any float type) so that the MAX over ranks needs no
         # collective of its own
         n_words = 3 * rows_max * W
-        mine = torch.empty(1, n_words + 2, dtype=full.dtype, device=full.device)
+        mine = torch.empty(1, n_words + 2 + (Gy if balance else 0), dtype=full.dtype, device=full.device)
         if y1 > y0:
             mine[0, :n_words].view(3, rows_max, W)[:, :y1 - y0] = full[:, y0:y1]
         needs = tuple(ctx.needs_input_grad[:8]) + ((bool(ctx.needs_input_grad[10]),) if raw else ())
@@ -196,7 +207,11 @@ class _ShardedRasterize(torch.autograd.Function):
         order, n_mine = backend.binned_prefix(frame) if want_prefix else (None, 0)
         mine[0, n_words].fill_(float(int(n_mine) >> 16))
         mine[0, n_words + 1].fill_(float(int(n_mine) & 0xFFFF))
-        gathered = comm.all_gather(mine)                        # [world, 3 * rows_max * W + 2]
+        if balance:          # this rank's per-tile-row work rides along; the sum over ranks is next frames' slab weights
+            mine[0, n_words + 2:] = backend.row_work(frame, (W + 15) // 16, Gy).to(mine.dtype)
+        gathered = comm.all_gather(mine)                        # [world, 3 * rows_max * W + 2 (+ Gy)]
+        if balance:
+            shard.set_row_work(gathered[:, n_words + 2:].sum(0))
         for r, (a, b) in enumerate(slabs):
             a_px, b_px = min(a * 16, H), min(b * 16, H)
             if b_px > a_px and r != comm.rank:
@@ -206,7 +221,7 @@ class _ShardedRasterize(torch.autograd.Function):
         if want_prefix:
             # longest binned depth prefix over the ranks: sizes the backward's gradient exchange; on its way to pinned
             # host memory now, so that the backward finds it without a stream drain
-            ctx.n_max = (order, comm.read_halves_later(gathered[:, n_words:]) if order is not None else None)
+            ctx.n_max = (order, comm.read_halves_later(gathered[:, n_words:n_words + 2]) if order is not None else None)
             hook = getattr(backend, "prepare_backward", None)       # the native provider zero-fills the backward's outputs now
             if hook is not None:
                 hook(frame, needs)
@@ -274,8 +289,12 @@ class ShardedRenderer:
     gaussian_renderer.render, reference gaussian_renderer/__init__.py:18-100)."""
 
     def __init__(self, dist, world: int, rank: int, backend=None, group=None, row_weights=None,
-                 backward_mode: str = "allreduce_screen"):
+                 backward_mode: str = "allreduce_screen", balance_every: int = 0):
+        """row_weights: fixed per-tile-row weights for the slab boundaries (None = equal rows).  balance_every = k > 0:
+        SURVEY 7 "slab load balance" — every k-th frame the ranks' measured per-tile-row work (instances binned) rides
+        on the all-gather and the next frames' slabs are cut at equal cumulative work."""
         assert backward_mode in ("allreduce_screen", "reduce_scatter")
+        self.balance_every, self._frames, self._pending = int(balance_every), 0, None
         self.comm = _Comm(dist, world, rank, group)
         self.backend = NativeBackend() if backend is None else backend
         self.row_weights = row_weights
@@ -295,6 +314,35 @@ class ShardedRenderer:
             return loss_utils.training_loss(image, gt, lambda_dssim)
         return loss_utils.training_loss_rows(image, gt, lambda_dssim, self.pixel_rows(int(image.shape[1])),
                                              lambda t: self.comm.all_reduce_sum(t))
+
+    def balance_now(self, Gy: int) -> bool:
+        """Called once per frame by the forward: adopt weights measured earlier, say whether this frame measures."""
+        if self.balance_every <= 0:
+            return False
+        if self._pending is not None:                       # measured on an earlier frame; host copy has long arrived
+            w = self._pending()
+            self._pending = None
+            if len(w) == Gy and sum(w) > 0:
+                floor = 0.01 * sum(w) / Gy                  # empty rows still cost a little: keep every weight positive
+                self.row_weights = [max(float(x), floor) for x in w]
+        self._frames += 1
+        return self._frames % self.balance_every == 1 or self.balance_every == 1
+
+    def set_row_work(self, work: torch.Tensor) -> None:
+        """work [Gy] (device or host): summed over ranks; reaches the host through pinned memory, read at a later frame."""
+        if work.device.type != "cuda":
+            w = [float(x) for x in work.tolist()]
+            self._pending = lambda: w
+            return
+        host = torch.empty(work.shape, dtype=torch.float32).pin_memory()
+        host.copy_(work.to(torch.float32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(work.device))
+
+        def read():
+            ev.synchronize()
+            return host.tolist()
+        self._pending = read
 
     def slabs(self, Gy: int):
         return slab_bounds(Gy, self.comm.world, self.row_weights if self.row_weights and len(self.row_weights) == Gy else None)

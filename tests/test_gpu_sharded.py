@@ -121,3 +121,76 @@ def test_slab_local_loss_pieces_add_up_to_the_full_loss():
         loss = 0.8 * sums[0] / n + 0.2 * (1 - sums[1] / n)
         assert abs(float(loss) - float(full.detach())) < 2e-6, (H, W)
         assert torch.allclose(grad, a.grad, rtol=1e-5, atol=1e-9), (H, W, float((grad - a.grad).abs().max()))
+
+
+def _balance_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussian_params import GaussianParams, Pipe
+        from diff_gaussian_rasterization.sharded import ShardedRenderer
+        from loss_utils import training_loss
+        dev = "cuda:0"
+        scene, cam = _uneven_scene()
+        cam = cam.to(dev)
+        model = GaussianParams(scene.to(dev)).to(dev)
+        bg = torch.zeros(3, device=dev)
+        gt = torch.rand(3, 304, 400, generator=torch.Generator().manual_seed(7)).to(dev)
+        sr = ShardedRenderer(dist, world, rank, balance_every=1)
+        hist = []
+        for it in range(3):
+            for p in model.parameters():
+                p.grad = None
+            out = sr.render(cam, model, Pipe(), bg)
+            hist.append(sr.pixel_rows(304))
+            sr.training_loss(out["render"], gt).backward()
+        torch.cuda.synchronize()
+        q.put((rank, dict(image=out["render"].detach().cpu().numpy(), rows=hist,
+                          grads={n: p.grad.cpu().numpy() for n, p in model.named_parameters()})))
+    finally:
+        dist.destroy_process_group()
+
+
+def _uneven_scene():
+    """Every Gaussian in the top third of the frame: equal-row slabs would leave the lower ranks idle."""
+    scene, cam = S.make_scene(30000, 400, 304, 1, 402, scale_lo=0.004, scale_hi=0.05), S.make_camera(400, 304)
+    scene.means3D[:, 1] = -scene.means3D[:, 1].abs() * 0.6 - 0.15 * scene.means3D[:, 2]
+    return scene, cam
+
+
+def test_slab_balancer_moves_the_boundaries_and_keeps_the_result():
+    """balance_every=1 with 3 ranks on a frame whose splats sit in the top third: after the first (equal-rows) frame the
+    measured per-tile-row work moves the slab boundaries up, on every rank alike; image and gradients still equal the
+    single-GPU step."""
+    from gaussian_params import GaussianParams, Pipe
+    from gaussian_renderer import render
+    from loss_utils import training_loss
+    world = 3
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_balance_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    dev = "cuda:0"
+    scene, cam = _uneven_scene()
+    model = GaussianParams(scene.to(dev)).to(dev)
+    gt = torch.rand(3, 304, 400, generator=torch.Generator().manual_seed(7)).to(dev)
+    out = render(cam.to(dev), model, Pipe(), torch.zeros(3, device=dev))
+    training_loss(out["render"], gt).backward()
+    want_img = out["render"].detach().cpu().numpy()
+    rows0 = [results[r]["rows"][0] for r in range(world)]
+    rows2 = [results[r]["rows"][2] for r in range(world)]
+    assert rows0 == [(0, 112), (112, 208), (208, 304)]                      # 19 tile rows split 7 / 6 / 6
+    assert rows2[0][1] < rows0[0][1] and rows2[1][1] < rows0[1][1]          # boundaries moved towards the busy top
+    assert rows2[0][0] == 0 and rows2[2][1] == 304 and rows2[0][1] == rows2[1][0] and rows2[1][1] == rows2[2][0]
+    for r in range(world):
+        assert np.array_equal(results[r]["image"], want_img)
+        for n, p in model.named_parameters():
+            w = p.grad.cpu().numpy()
+            scale = max(np.abs(w).max(), 1e-30)
+            assert np.abs(results[r]["grads"][n] - w).max() <= 5e-6 * scale, (r, n)
