@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL process group, ShardedRenderer, slab-local loss) "
@@ -67,23 +67,36 @@ def main():
                     help="also time ITERS iterations of the full training loop (Adam, densify every 100) on the workload")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started by hand: become the launcher.  Nothing in this process has touched the GPU
+        # (importing torch and counting devices does not initialise HIP); the ranks are fresh children.
+        sys.exit(_self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    n_dev = max(torch.cuda.device_count(), 1)
+    shared_device = world > n_dev          # rehearsal on a box with fewer GPUs than ranks: ranks share devices
+    torch.cuda.set_device(local_rank % n_dev)
+    dev = torch.device("cuda", local_rank % n_dev)
     dist = None
+    collectives = None
     if world > 1 or args.force_sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            collectives = "rccl (world 1)"
+        elif shared_device:
+            # RCCL refuses two ranks on one device: the rehearsal stages the collectives through gloo (sharded._Comm
+            # does that when the group's backend is gloo).  Never the case on the driver's N-GPU node.
+            dist.init_process_group("gloo")
+            collectives = f"gloo (REHEARSAL: {world} ranks share {n_dev} device(s); not a scaling measurement)"
         else:
             dist.init_process_group("nccl", device_id=dev)
+            collectives = "rccl"
 
     import scene_synth as S
     from diff_gaussian_rasterization import _native as N
@@ -181,7 +194,7 @@ def main():
                          "what": "unchanged caller (reference-style render(): getters + GaussianRasterizer.forward) with "
                                  "diff_gaussian_rasterization.FUSE_GETTERS = True (or GSR_FUSE_GETTERS=1)"}
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -246,7 +259,8 @@ def main():
                                f"(SURVEY Appendix B seed {cfg['seed']}); step = render() + L1/D-SSIM loss + backward "
                                f"(train.py:79-108 window)",
                    "visible": V, "num_rendered": R, "instances_emitted": Re, "chunks_run": stats["chunks_run"],
-                   "parallelism": "single" if sharded is None else f"tile-row slabs x{world}"},
+                   "parallelism": "single" if sharded is None else f"tile-row slabs x{world}",
+                   **({"collectives": collectives} if collectives else {})},
         "raster_ms_per_step": round(raster_ms, 4), "profiled_ms_per_step": round(1e3 * elapsed_profiled / args.steps, 4),
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
                     for k, v in per_kernel.items()},
@@ -262,6 +276,27 @@ def main():
     print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def _self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a CHILD process (never exec: see the GPU box rules) and relay its output; rank 0 of the child
+    job prints the JSON line.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in p.stdout.splitlines():
+        print(ln, flush=True)
+    return p.returncode
 
 
 def _frame_stats(model, cam, bg, pipe):
@@ -395,7 +430,33 @@ def _cpu_baseline(scene, cam, cfg):
     return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"1 frame of the same workload, rasterizer forward+backward only (no loss), C oracle with "
                       f"OpenMP over {cores} host threads (sort and per-Gaussian stages serial); {dt:.1f} s",
-            "python_sh_path_ms": round(sh_ms, 1), "torch_threads": torch.get_num_threads()}
+            "python_sh_path_ms": round(sh_ms, 1), "torch_threads": torch.get_num_threads(),
+            "cfg1": _cpu_baseline_cfg1()}
+
+
+def _cpu_baseline_cfg1():
+    """BASELINE.json configs[0] as BASELINE.md section 3 planned it: 10 k Gaussians, SH degree 0, 256x256, CPU rasterize
+    FORWARD only (plumbing) — the C oracle, 3 warm-up + 10 timed frames, single thread and all threads."""
+    import numpy as np
+
+    import oracle
+    import scene_synth as S
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import raster_kwargs
+    scene, cam = S.make_config("cfg1")
+    kw = raster_kwargs(scene, cam)
+    out = {"workload": "cfg1: 10000 Gaussians, SH degree 0, 256x256, forward only", "kind": "port", "unit": "images/s"}
+    for label, par in (("1_thread", False), ("all_threads", True)):
+        ts = []
+        for i in range(13):
+            t0 = time.perf_counter()
+            oracle.rasterize(dtype=np.float32, parallel=par, **kw)
+            if i >= 3:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out[label] = {"median_ms": round(1e3 * ts[len(ts) // 2], 2), "min_ms": round(1e3 * ts[0], 2),
+                      "value": round(1.0 / ts[len(ts) // 2], 2)}
+    return out
 
 
 if __name__ == "__main__":

@@ -341,8 +341,23 @@ static void FN(render_tile)(FN(ctx) *c, int tx, int ty, int64_t *pairs_out)
             c->n_contrib[pix] = last;
             c->fragile_px[pix] = fragile;
             for (int ch = 0; ch < 3; ++ch) c->color[(size_t)ch * H * W + pix] = C[ch] + T * c->bg[ch];
-            if (fragile)
-                for (int64_t j = start; j < end; ++j) c->fragile_g[c->vals[j]] = 1;
+            if (fragile) {
+                /* Only Gaussians that can REACH this pixel are affected by a flipped decision: those whose
+                 * alpha here is >= 1/255 (within the band), anywhere in the tile's list -- a flipped stop
+                 * decision lets later splats in.  A race on the byte store is benign (all writers store 1). */
+                for (int64_t j = start; j < end; ++j) {
+                    uint32_t g = c->vals[j];
+                    REAL dx = c->xy[2 * g] - (REAL)px, dy = c->xy[2 * g + 1] - (REAL)py;
+                    const REAL *co = c->conic_op + 4 * g;
+                    REAL qa = (REAL)0.5 * co[0] * dx * dx, qc = (REAL)0.5 * co[2] * dy * dy, qb = co[1] * dx * dy;
+                    REAL power = -(REAL)0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    REAL mag = R_FABS(qa) + R_FABS(qc) + R_FABS(qb);
+                    if (power > eps * mag) continue;
+                    REAL alpha = co[3] * R_EXP(power > 0 ? 0 : power);
+                    if (alpha * 255 - 1 < -eps * (1 + mag)) continue;
+                    c->fragile_g[g] = 1;
+                }
+            }
         }
     *pairs_out = pairs;
 }
