@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py — train-step images/s (fwd+bwd) of the Gaussian-rasterizer hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3] [--no-cpu-baseline] [--no-secondary]
 
 A "step" is the reference's timed training window (train.py:79-108): render() through the drop-in
 rasterizer + L1/D-SSIM loss + backward into the leaf parameters, on BASELINE.json configs[2]'s scene
 (1e6 Gaussians, 1920x1080, SH degree 3; SURVEY Appendix B, seed 3).  Inputs are resident in HBM before
-the timed region.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the image is split
-into tile-row slabs: the scene is fixed and each rank renders its slab of the SAME image, so
-scaling is "strong".
+the timed region.  For N > 1 the image is split into tile-row slabs: the scene is fixed and each
+rank renders its slab of the SAME image, so scaling is "strong".  `python bench.py --gpus N` without a launcher
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself (as a child process).
 
-Prints ONE JSON line on rank 0 (see the keys at the bottom).  The roofline object is for the dominant
-kernel of the step, timed live with hipEvents inside libgsrast.so; cpu_baseline times the CPU oracle
-(a port, test infrastructure) on rank 0 at N = 1 only.
+Prints ONE JSON line on rank 0.  Besides the contract's keys:
+  roofline      dominant kernel of the step, timed live with hipEvents inside libgsrast.so; `valu` prices the blend
+                kernel's measured instruction mix (profiles/r02_valu_mix.json) with the issue rates measured by
+                profiles/valu_microbench on this chip
+  cpu_baseline  the CPU oracle (a port, test infrastructure) on rank 0 at N = 1 only; .cfg1 = BASELINE configs[0]
+  secondary     the same step on a NON-saturating scene (scene_synth CONFIGS["cfg3n"]: R/P = 3.6, 98 % of the visible
+                Gaussians receive a gradient) with its own per-kernel table and roofline, and cfg3 with another seed
+  reference_loss_composition   the step with the reference's own two-call loss (l1_loss + ssim: utils/loss_utils.py)
 """
 import argparse
 import json
@@ -31,25 +36,31 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def algorithmic_bytes(P, V, Re, N, Tn, K, M, Vlive, C=3):
-    """ALGORITHMIC bytes per step and kernel: SURVEY.md 8d's per-unit figures x the units each kernel
-    processes in THIS design.  Re = instances actually emitted by the progressive
-    binning (the reference would process R = num_rendered of them), Vlive = Gaussians with a non-zero
-    screen-space gradient.  Keys are the library's profile names; values are totals per step."""
+def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, C=3):
+    """ALGORITHMIC bytes per step and kernel: SURVEY.md 8d's per-unit figures x the units each kernel processes in THIS
+    design.  P Gaussians, V visible, Vb = Gaussians of the depth chunks that were binned (the
+    depth prefix), Re = instances actually emitted by the progressive binning (the reference would process R =
+    num_rendered of them), Vlive = Gaussians with a non-zero screen-space gradient, N pixels, Tn tiles.  Every logical
+    array is charged once per read and once per write, to the kernel that moves it: zero rows are charged to
+    `zero_outputs` when the early fill runs (then NOT to geom_bwd), SH coefficients to `chunk_colors` (the lazy colour
+    pass reads them for binned Gaussians only), never to `preprocess`."""
+    geom_rows = Vb if sparse_geom else P                    # rows the geometry backward visits
+    geom_written = Vlive if prezeroed else geom_rows        # after an early fill only live rows are written
     return {
-        "preprocess": 52 * P + (12 * K + 67) * V,          # K1 (+ 8 B/Gaussian depth-sort key/value)
+        "preprocess": 52 * P + 67 * V,                      # K1 minus A.6: read 44 + sort key/value 8, write 67 per visible
+        "chunk_colors": (12 * K + 12 + 12 + 1) * Vb,        # A.6 for binned Gaussians: SH + mean in, rgb + clamp mask out
         "depth_sort": 16 * P,                               # minimum: one read + one write of (key, value)
         "scan_tiles": 12 * P, "chunk_plan": 0, "open_count": 8 * Tn,    # the scan gathers tiles[order[r]] itself
-        "count_open": 56 * V, "scan_open": 8 * V,
-        "emit": 12 * Re,                                    # K3: key 4 + slot 4 + Gaussian 4 per instance
+        "count_open": 56 * Vb, "scan_open": 8 * Vb,         # rank -> Gaussian 4 + record 48 + count 4
+        "emit": 12 * Re + 56 * Vb,                          # K3: key 4 + slot 4 + Gaussian 4 per instance
         "tile_sort": 16 * Re,                               # K4 minimum: one read + one write of (tile, slot)
         "ranges": 16 * Re + 8 * Tn,                         # K5 (+ sorted position -> Gaussian)
         "render_fwd": 40 * Re + 20 * N,                     # K6: id 4 + record 36 per instance; 20 B/px
         "render_bwd": 76 * Re + 20 * N,                     # K7: 40 read + 36 written per instance; 20 B/px
-        "reduce_rows": 36 * Re + 36 * P,                    # deterministic reduction (replaces atomic RMW)
-        "geom_bwd": 4 * P + (99 + 12 * K) * Vlive + (40 + 12 * M) * P,   # K8 + K9
+        "reduce_rows": 36 * Re + 36 * Vb,                   # deterministic reduction (replaces atomic RMW)
+        "geom_bwd": 4 * geom_rows + (99 + 12 * K) * Vlive + (40 + 12 * M) * geom_written,        # K8 + K9
         "loss_fwd": 20 * C * N, "loss_bwd": 24 * C * N,
-        "zero_outputs": (104 + 12 * M) * P,                # early zero fill: screen-space (48 B) + parameter gradients
+        "zero_outputs": (104 + 12 * M) * P if prezeroed else 0,      # early fill: screen-space (48 B) + parameter gradients
     }
 
 
@@ -58,8 +69,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg3n", "cfg3b", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the non-saturating scene and the second seed")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL process group, ShardedRenderer, slab-local loss) "
                          "with world_size 1")
@@ -98,36 +110,82 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
             collectives = "rccl"
 
+    ctx = dict(dev=dev, dist=dist, world=world, rank=rank, sharded_on=(world > 1 or args.force_sharded))
+    single = world == 1 and not args.force_sharded
+    m = measure(args.workload, args.steps, args.warmup, ctx, extras=single, traffic=(args.workload == "cfg3" and world == 1))
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    line = {
+        "metric": "train-step images/sec (fwd+bwd) @1080p, 1e6 Gaussians" if args.workload == "cfg3"
+        else f"train-step images/sec (fwd+bwd) {args.workload}",
+        "value": m["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": m["ms_per_step"], "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {**m["config"], "parallelism": "single" if not ctx["sharded_on"] else f"tile-row slabs x{world}",
+                   **({"collectives": collectives} if collectives else {})},
+        "raster_ms_per_step": m["raster_ms_per_step"], "profiled_ms_per_step": m["profiled_ms_per_step"],
+        "kernels": m["kernels"], "roofline": m["roofline"], "cpu_baseline": None,
+    }
+    for k in ("fused_activations", "getter_fusion", "reference_loss_composition"):
+        if m.get(k) is not None:
+            line[k] = m[k]
+    if single and not args.no_secondary and args.workload == "cfg3":
+        sec = measure("cfg3n", args.steps, args.warmup, ctx, extras=False, traffic=False)
+        other = measure("cfg3b", max(args.steps // 2, 2), 2, ctx, extras=False, traffic=False, profile=False)
+        line["secondary"] = {
+            "what": "the same step on a scene that does NOT saturate: the cfg3 generator with z ~ U(2, 6) and scales x0.5 "
+                    "(scene_synth.CONFIGS['cfg3n']); every constant of the library at its default",
+            "value": sec["value"], "unit": "images/s", "ms_per_step": sec["ms_per_step"], "config": sec["config"],
+            "raster_ms_per_step": sec["raster_ms_per_step"], "kernels": sec["kernels"], "roofline": sec["roofline"],
+            "other_seed": {"what": "cfg3's generator, seed 33 instead of 3", "value": other["value"],
+                           "ms_per_step": other["ms_per_step"], "config": other["config"]},
+        }
+    if single and args.train_loop > 0:
+        line["train_loop"] = _train_loop(args.workload, args.train_loop, dev, False)
+        line["train_loop"]["fused_activations"] = _train_loop(args.workload, args.train_loop, dev, True)
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = _cpu_baseline(args.workload)
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
+    """Time `steps` steps of the training window on `workload`; returns the numbers of one bench object."""
     import scene_synth as S
     from diff_gaussian_rasterization import _native as N
     from gaussian_params import GaussianParams, Pipe
     from gaussian_renderer import render
     from loss_utils import training_loss
+    dev, dist, world, rank = ctx["dev"], ctx["dist"], ctx["world"], ctx["rank"]
 
-    cfg = S.CONFIGS[args.workload]
-    scene, cam = S.make_config(args.workload)
+    cfg = S.CONFIGS[workload]
+    scene, cam = S.make_config(workload)
     scene, cam = scene.to(dev), cam.to(dev)
     model = GaussianParams(scene).to(dev)
     params = [p for p in model.parameters()]
     bg = torch.zeros(3, device=dev)
     gt = torch.rand(3, cfg["H"], cfg["W"], generator=torch.Generator().manual_seed(cfg["seed"] + 100)).to(dev)
     pipe = Pipe()
-
-    if world > 1 or args.force_sharded:
+    sharded = None
+    if ctx["sharded_on"]:
         from diff_gaussian_rasterization.sharded import ShardedRenderer
         sharded = ShardedRenderer(dist, world, rank)
-    else:
-        sharded = None
+    loss_fn = {"f": None}
 
     def step():
         for p in params:
             p.grad = None
-        if sharded is None:
-            out = render(cam, model, pipe, bg)
-        else:
-            out = sharded.render(cam, model, pipe, bg)
+        out = render(cam, model, pipe, bg) if sharded is None else sharded.render(cam, model, pipe, bg)
         # same loss; on N > 1 every rank evaluates the terms of its own rows (slab-local, one 8-byte all-reduce)
-        loss = training_loss(out["render"], gt) if sharded is None else sharded.training_loss(out["render"], gt)
+        if loss_fn["f"] is not None:
+            loss = loss_fn["f"](out["render"], gt)
+        else:
+            loss = training_loss(out["render"], gt) if sharded is None else sharded.training_loss(out["render"], gt)
         loss.backward()
         return out
 
@@ -137,62 +195,63 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
+    def timed(n, w):
+        for _ in range(w):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            o = step()
+        sync()
+        return time.perf_counter() - t0, o
+
     # (1) the timed region: EXACTLY K steps, no instrumentation inside
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed, out = timed(steps, warmup)
     # (2) the same K steps again with the library's per-kernel hipEvent pairs (roofline); the event packets
     # add ~10 us between kernels, so this pass is reported separately and never feeds `value`
-    N.profile_enable(True)
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    elapsed_profiled = time.perf_counter() - t1
-    prof = N.profile_read()
-    N.profile_enable(False)
-    # (3) extension, reported beside `value`, never as it: the same K steps with the activations of the parameter
-    # store (exp / sigmoid / normalize / cat and their backward) fused into the HIP kernels
-    # (pipe.fused_activations -> GaussianRasterizer.forward_raw) instead of running as ~30 torch kernels
-    fused = None
-    if sharded is None:
+    prof, elapsed_profiled = {}, 0.0
+    if profile:
+        N.profile_enable(True)
+        elapsed_profiled, out = timed(steps, 0)
+        prof = N.profile_read()
+        N.profile_enable(False)
+    res = {}
+    if extras:
+        # (3) extension, reported beside `value`, never as it: the activations of the parameter store
+        # fused into the HIP kernels (pipe.fused_activations -> GaussianRasterizer.forward_raw)
         pipe.fused_activations = True
-        for _ in range(max(args.warmup, 1)):
-            step()
-        sync()
-        t2 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        el = time.perf_counter() - t2
+        el, _ = timed(steps, max(warmup, 1))
         pipe.fused_activations = False
-        fused = {"value": round(args.steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / args.steps, 4),
-                 "what": "same step, activations fused into preprocess / geometry-backward kernels (extension beyond the "
-                         "reference API: render(..., pipe.fused_activations=True)); same image and parameter gradients"}
-    # (4) extension, also reported beside `value`: the SAME caller code as the timed pass (getters + standard forward()),
-    # with the rasterizer's opt-in FUSE_GETTERS: it recognises the getters in the arguments' autograd history and renders
-    # from the leaves, so the getters' backward kernels (and cat's copies) never run
-    getter_fusion = None
-    if sharded is None:
+        res["fused_activations"] = {
+            "value": round(steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / steps, 4),
+            "what": "same step, activations fused into preprocess / geometry-backward kernels (extension beyond the "
+                    "reference API: render(..., pipe.fused_activations=True)); same image and parameter gradients"}
+        # (4) the SAME caller code as the timed pass with the rasterizer's opt-in FUSE_GETTERS
         import diff_gaussian_rasterization as _dgr
         _dgr.FUSE_GETTERS = True
-        for _ in range(max(args.warmup, 1)):
-            step()
-        sync()
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        el = time.perf_counter() - t3
+        el, _ = timed(steps, max(warmup, 1))
         _dgr.FUSE_GETTERS = False
-        getter_fusion = {"value": round(args.steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / args.steps, 4),
-                         "what": "unchanged caller (reference-style render(): getters + GaussianRasterizer.forward) with "
-                                 "diff_gaussian_rasterization.FUSE_GETTERS = True (or GSR_FUSE_GETTERS=1)"}
+        res["getter_fusion"] = {
+            "value": round(steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / steps, 4),
+            "what": "unchanged caller (reference-style render(): getters + GaussianRasterizer.forward) with "
+                    "diff_gaussian_rasterization.FUSE_GETTERS = True (or GSR_FUSE_GETTERS=1); opt-in: matches autograd node "
+                    "names, falls back to the plain path on any mismatch"}
+        # (5) the reference's own loss composition, train.py:104-105 verbatim: Ll1 = l1_loss(image, gt);
+        # loss = (1 - lambda) * Ll1 + lambda * (1 - ssim(image, gt)) with this package's drop-in l1_loss / ssim
+        import loss_utils
+        if hasattr(loss_utils, "ssim_torch"):
+            loss_fn["f"] = lambda image, g: (1.0 - 0.2) * loss_utils.l1_loss(image, g) + 0.2 * (1.0 - loss_utils.ssim(image, g))
+            el, _ = timed(steps, max(warmup, 1))
+            loss_fn["f"] = lambda image, g: loss_utils.training_loss_torch(image, g)
+            n_torch = max(steps // 2, 2)
+            el_torch, _ = timed(n_torch, 1)
+            loss_fn["f"] = None
+            res["reference_loss_composition"] = {
+                "value": round(steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / steps, 4),
+                "what": "train.py:104-105 as written (two calls: l1_loss, ssim) with loss_utils' drop-in autograd ops over "
+                        "the fused kernels; torch_ops_ms_per_step = the same composition in plain torch ops (5 depthwise "
+                        "convolutions and their backward), what an import of the reference's own utils/loss_utils.py gives",
+                "torch_ops_ms_per_step": round(1e3 * el_torch / n_torch, 4)}
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,76 +265,56 @@ def main():
     K = M = (cfg["D"] + 1) ** 2
     stats = _frame_stats(model, cam, bg, pipe)
     R, Re, Vlive, pairs = stats["num_rendered"], stats["emitted"], stats["live"], stats["pairs_bwd"]
-    alg = algorithmic_bytes(P, V, Re, Npix, Tn, K, M, Vlive)
+    Vb = stats["binned_ranks"]
+    sparse = Vb * 4 < P
+    alg = algorithmic_bytes(P, V, Vb, Re, Npix, Tn, K, M, Vlive, sparse_geom=sparse, prezeroed=sparse)
     per_kernel = {}
     for k, (ms, n) in prof.items():
-        per_step_ms = ms / args.steps
-        per_kernel[k] = dict(ms_per_step=per_step_ms, launches_per_step=n / args.steps,
+        per_step_ms = ms / steps
+        per_kernel[k] = dict(ms_per_step=per_step_ms, launches_per_step=n / steps,
                              alg_GBs=(alg.get(k, 0) / 1e9) / (per_step_ms / 1e3) if per_step_ms > 0 else None)
         keys = {"depth_sort": P, "tile_sort": Re}.get(k)             # SURVEY 8d secondary rate for K4: keys/s
         if keys is not None and per_step_ms > 0:
             per_kernel[k]["Gkeys_per_s"] = keys / 1e9 / (per_step_ms / 1e3)
-    raster_ms = sum(ms for ms, _ in prof.values()) / args.steps
-    dom = max(prof, key=lambda k: prof[k][0])
-    launches = max(prof[dom][1], 1)
-    dom_ms = prof[dom][0] / launches                              # average duration of one launch
-    bytes_per_launch = alg.get(dom, 0) * args.steps / launches
-    achieved = (bytes_per_launch / 1e9) / (dom_ms / 1e3)
-    roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 5), traffic=_traffic_from_profiles(dom) if (args.workload == "cfg3" and world == 1) else None,
-                    avg_launch_ms=round(dom_ms, 4), algorithmic_bytes_per_launch=int(bytes_per_launch),
-                    step_algorithmic_bytes=int(sum(alg.values())),
-                    step_frac=round(sum(alg.values()) / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 5),
-                    # context only: SURVEY 8d's whole-step total evaluated as the REFERENCE's algorithm would move it, i.e.
-                    # with all R = num_rendered duplicates (this design bins `instances_emitted` of them), over the same time
-                    reference_formula_step_bytes=int((144 + 12 * M) * P + (182 + 24 * K) * V + 160 * R + 40 * Npix + 8 * Tn),
-                    reference_formula_step_frac=round(((144 + 12 * M) * P + (182 + 24 * K) * V + 160 * R + 40 * Npix + 8 * Tn)
-                                                      / 1e9 / (elapsed / args.steps) / HBM_PEAK_GBS, 5),
-                    note="blend kernels are VALU-bound (SURVEY 8d caveat): secondary rate = "
-                         f"{pairs / 1e9 / (per_kernel.get('render_bwd', {}).get('ms_per_step', 0) / 1e3 + 1e-12):.1f} "
-                         "G (pixel,splat) pairs/s in render_bwd")
-
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    train_loop = None
-    if world == 1 and args.train_loop > 0:
-        train_loop = _train_loop(args.workload, args.train_loop, dev, False)
-        train_loop["fused_activations"] = _train_loop(args.workload, args.train_loop, dev, True)
-
-    cpu_baseline = None
-    if world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = _cpu_baseline(scene, cam, cfg)
-
-    line = {
-        "metric": "train-step images/sec (fwd+bwd) @1080p, 1e6 Gaussians" if args.workload == "cfg3"
-        else f"train-step images/sec (fwd+bwd) {args.workload}",
-        "value": round(args.steps / elapsed, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {P} Gaussians, {cfg['W']}x{cfg['H']}, SH degree {cfg['D']} "
-                               f"(SURVEY Appendix B seed {cfg['seed']}); step = render() + L1/D-SSIM loss + backward "
-                               f"(train.py:79-108 window)",
+    raster_ms = sum(ms for ms, _ in prof.values()) / steps
+    roofline = None
+    if prof:
+        dom = max(prof, key=lambda k: prof[k][0])
+        launches = max(prof[dom][1], 1)
+        dom_ms = prof[dom][0] / launches                              # average duration of one launch
+        bytes_per_launch = alg.get(dom, 0) * steps / launches
+        achieved = (bytes_per_launch / 1e9) / (dom_ms / 1e3)
+        bwd_ms = per_kernel.get("render_bwd", {}).get("ms_per_step", 0)
+        ref_bytes = (144 + 12 * M) * P + (182 + 24 * K) * V + 160 * R + 40 * Npix + 8 * Tn
+        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=_traffic_from_profiles(dom) if traffic else None,
+                        avg_launch_ms=round(dom_ms, 4), algorithmic_bytes_per_launch=int(bytes_per_launch),
+                        step_algorithmic_bytes=int(sum(alg.values())),
+                        step_frac=round(sum(alg.values()) / 1e9 / (elapsed / steps) / HBM_PEAK_GBS, 5),
+                        # context only: SURVEY 8d's whole-step total evaluated as the REFERENCE's algorithm would move it
+                        # (all R = num_rendered duplicates; this design bins `instances_emitted` of them), over the same time
+                        reference_formula_step_bytes=int(ref_bytes),
+                        reference_formula_step_frac=round(ref_bytes / 1e9 / (elapsed / steps) / HBM_PEAK_GBS, 5),
+                        valu=_valu_roofline(dom, dom_ms, workload) if traffic else None,
+                        pairs_per_s_G=round(pairs / 1e9 / (bwd_ms / 1e3), 1) if bwd_ms > 0 else None,
+                        note="the blend kernels are VALU-issue-bound, not HBM-bound (SURVEY 8d caveat): `valu` is their "
+                             "roofline; pairs_per_s_G = (pixel, splat) pairs per second in render_bwd")
+    res.update({
+        "value": round(steps / elapsed, 3), "ms_per_step": round(1e3 * elapsed / steps, 4),
+        "config": {"workload": f"{workload}: {P} Gaussians, {cfg['W']}x{cfg['H']}, SH degree {cfg['D']} "
+                               f"(SURVEY Appendix B generator, seed {cfg['seed']}"
+                               + (f", z >= {cfg['zmin']}, scales x{cfg['scale_mul']}" if "zmin" in cfg else "")
+                               + "); step = render() + L1/D-SSIM loss + backward (train.py:79-108 window)",
                    "visible": V, "num_rendered": R, "instances_emitted": Re, "chunks_run": stats["chunks_run"],
-                   "parallelism": "single" if sharded is None else f"tile-row slabs x{world}",
-                   **({"collectives": collectives} if collectives else {})},
-        "raster_ms_per_step": round(raster_ms, 4), "profiled_ms_per_step": round(1e3 * elapsed_profiled / args.steps, 4),
-        "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()}
-                    for k, v in per_kernel.items()},
+                   "chunks_planned": stats["chunks_planned"], "binned_gaussians": Vb, "gaussians_with_gradient": Vlive,
+                   "emitted_over_num_rendered": round(Re / max(R, 1), 4)},
+        "raster_ms_per_step": round(raster_ms, 4), "profiled_ms_per_step": round(1e3 * elapsed_profiled / steps, 4),
+        "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in per_kernel.items()},
         "roofline": roofline,
-        "cpu_baseline": cpu_baseline,
-    }
-    if fused is not None:
-        line["fused_activations"] = fused
-    if getter_fusion is not None:
-        line["getter_fusion"] = getter_fusion
-    if train_loop is not None:
-        line["train_loop"] = train_loop
-    print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    })
+    del model, params, scene, gt, out
+    torch.cuda.empty_cache()
+    return res
 
 
 def _self_launch(n: int) -> int:
@@ -330,8 +369,9 @@ def _frame_stats(model, cam, bg, pipe):
         g = torch.ones(3, H, W, device=enc.device)
         screen = dgr.rasterize_backward_screen(fr, g)
         live = int((screen.abs().sum(1) > 0).sum())
-    return dict(num_rendered=fr.R, emitted=emitted, chunks_run=int(fr.plan.chunks_run), live=live,
-                pairs_bwd=int(ncontrib.sum()))
+        binned = int(fr.plan.chunk_rank_begin[fr.plan.chunks_run]) if fr.plan.num_rendered > 0 and fr.plan.chunks_run > 0 else 0
+    return dict(num_rendered=fr.R, emitted=emitted, chunks_run=int(fr.plan.chunks_run), chunks_planned=int(fr.plan.num_chunks),
+                live=live, pairs_bwd=int(ncontrib.sum()), binned_ranks=binned)
 
 
 def _train_loop(workload, iters, dev, fused):
@@ -354,7 +394,7 @@ def _train_loop(workload, iters, dev, fused):
         targets = [render(c, truth, Pipe(), bg)["render"].clone() for c in cams]
     del truth
     gm = GaussianModel(cfg["D"])
-    gm.adopt_scene(S.make_scene(cfg["P"], cfg["W"], cfg["H"], cfg["D"], cfg["seed"]), device=dev)
+    gm.adopt_scene(S.make_config(workload)[0], device=dev)
     opt = replace(OptimizationDefaults(), densify_from_iter=0)
     gm.training_setup(opt)
     warm = min(20, iters // 4)
@@ -384,35 +424,62 @@ def _train_loop(workload, iters, dev, fused):
             "includes": "LR schedule, render, L1/D-SSIM, backward, densification stats, densify+prune every 100 it, Adam"}
 
 
-def _traffic_from_profiles(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json: FETCH_SIZE x2 +
-    WRITE_SIZE, made by profiles/pmc_to_traffic.py for the default cfg3 single-GPU run), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+def _profiles_json(name):
+    path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         try:
-            return json.load(open(path)).get(kernel)
+            return json.load(open(path))
         except Exception:
             return None
     return None
 
 
-def _cpu_baseline(scene, cam, cfg):
+def _traffic_from_profiles(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json: FETCH_SIZE x2 +
+    WRITE_SIZE, made by profiles/pmc_to_traffic.py for the default cfg3 single-GPU run), or None."""
+    d = _profiles_json("traffic.json")
+    return d.get(kernel) if d else None
+
+
+def _valu_roofline(kernel, launch_ms, workload):
+    """VALU-issue roofline of the dominant (blend) kernel.  Inputs, both committed under profiles/ and measured on MI355X:
+      * valu_microbench/r02_valu_rates.json — wave-instructions per cycle per SIMD for each instruction class at 4
+        resident waves per SIMD (profiles/valu_microbench/valu_microbench.hip), i.e. the issue cycles one wave64
+        instruction of that class occupies its SIMD;
+      * r02_valu_mix.json — for the default cfg3 run: the kernel's VALU wave-instructions per launch (rocprofv3 PMC
+        SQ_INSTS_VALU) and the share of each class (static count over the blend loop's disassembly), made by
+        profiles/valu_mix.py.
+    required = sum over classes of instructions x issue cycles; available = SIMDs x cycles of the launch.
+    `frac` = required / available: 1.0 would mean every SIMD issues a VALU instruction on every cycle of the launch."""
+    rates, mix = _profiles_json("valu_microbench/r02_valu_rates.json"), _profiles_json("r02_valu_mix.json")
+    if not rates or not mix or kernel not in mix.get("kernels", {}) or mix.get("workload", "cfg3") != workload:
+        return None
+    k = mix["kernels"][kernel]
+    clock_hz = float(rates.get("clock_hz", 2.4e9))
+    simds = int(rates.get("simds", 1024))
+    cyc = {name: 1.0 / r["w4"]["per_cycle_per_simd"] for name, r in rates["rates"].items() if r.get("w4", {}).get("per_cycle_per_simd")}
+    required = sum(k["insts_valu"] * share * cyc.get(cls, cyc.get("v_fma_f32", 2.0)) for cls, share in k["class_share"].items())
+    available = simds * launch_ms * 1e-3 * clock_hz
+    return {"kernel": kernel, "unit": "VALU issue cycles per launch", "achieved": int(required), "peak": int(available),
+            "frac": round(required / available, 4), "insts_valu_per_launch": int(k["insts_valu"]),
+            "clock_hz": clock_hz, "class_share": k["class_share"],
+            "issue_cycles_per_class": {c: round(cyc[c], 3) for c in k["class_share"] if c in cyc}}
+
+
+def _cpu_baseline(workload):
     """The CPU oracle (oracle/, a plain-C port of the algorithm; the reference has no CPU rasterizer:
     SURVEY F4) timed on the host cores: ONE frame of the same workload, rasterizer forward+backward."""
-    import math
-
     import numpy as np
 
     import oracle
-    oracle.build()
-    a = scene.to("cpu").activated()
-    cam = cam.to("cpu")
-    kw = dict(image_height=cfg["H"], image_width=cfg["W"], tanfovx=math.tan(cam.FoVx * .5), tanfovy=math.tan(cam.FoVy * .5),
-              bg=np.zeros(3), scale_modifier=1.0, viewmatrix=cam.world_view_transform.numpy(),
-              projmatrix=cam.full_proj_transform.numpy(), sh_degree=cfg["D"], campos=cam.camera_center.numpy(),
-              means3D=a["means3D"].numpy(), opacities=a["opacities"].numpy(), shs=a["shs"].numpy(),
-              scales=a["scales"].numpy(), rotations=a["rotations"].numpy())
     import scene_synth as S
+    oracle.build()
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import raster_kwargs
+    cfg = S.CONFIGS[workload]
+    scene, cam = S.make_config(workload)
+    kw = raster_kwargs(scene, cam)
+    a = scene.activated()
     g = S.make_grad_image(cfg["W"], cfg["H"], cfg["seed"]).numpy()
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()

@@ -175,7 +175,7 @@ int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, c
  * workspaces (no data is copied).  Any out-pointer may be NULL. */
 typedef struct gsr_debug_views {
     const float *splat_records;   /* [P,12]: x, y, conicA, conicB, conicC, opacity, r, g, b, depth, packed tile rect (2) */
-    const uint32_t *tiles_touched; /* [P]  by Gaussian */
+    const uint32_t *tiles_touched; /* [P,2] by Gaussian: (tiles touched, optical mass in 1/64 pixel-neper units) */
     const uint32_t *depth_order;   /* [P]  depth rank -> Gaussian (invisible ones last)                   */
     const uint32_t *point_offsets; /* [P]  inclusive scan of tiles touched, in depth order               */
     const uint8_t *clamped;        /* [P]  bit c set <=> channel c clamped */

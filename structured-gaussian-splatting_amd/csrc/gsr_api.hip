@@ -430,7 +430,7 @@ int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const v
     if (geom_ws) {
         GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
         v->splat_records = reinterpret_cast<const float *>(gw.records);
-        v->tiles_touched = gw.tiles_touched; v->depth_order = gw.order; v->point_offsets = gw.offs_full;
+        v->tiles_touched = reinterpret_cast<const uint32_t *>(gw.tiles_mass); v->depth_order = gw.order; v->point_offsets = gw.offs_full;
         v->clamped = gw.clamped;
     }
     if (binning_ws) {

@@ -8,10 +8,12 @@
 // 1.4 M of the 43.8 M instances can ever touch a pixel.  So:
 //
 //   1. sort the P Gaussians ONCE by depth (32-bit keys, invisible ones last)           [P-sized]
-//   2. inclusive scan of tiles touched in depth order; plan depth chunks by cumulative instance count:
-//      the first holds ~384 instances per tile of the slab (at least 1 M, at most R/8), each further one
-//      4x more: every chunk costs ~16 small launches (~100 us of fixed time) while an instance costs
-//      ~0.1 ns, so few and large chunks win, but tiles saturate after a few hundred splats    [P-sized]
+//   2. inclusive scan of tiles touched in depth order; plan depth chunks by cumulative OPTICAL MASS: a pixel takes
+//      the transmittance cut-off once the optical depths in front of it sum to ln(1e4) = 9.21, so the first chunk
+//      ends where the frame's mean optical depth (running sum of the splats' optical masses / slab pixels,
+//      gsr_math.h optical_mass) reaches kChunkOpticalDepths x 9.21, each further one at 4x more; a frame whose
+//      total never gets there (a scene that does not saturate) is ONE chunk.  Every chunk costs ~16 small
+//      launches (~100 us of fixed time) while an instance costs ~0.1 ns, so few and large chunks win   [P-sized]
 //   3. per chunk: count the instances each Gaussian emits (tiles of its rectangle that are OPEN and that its
 //      alpha >= 1/255 ellipse can reach: exact tile culling), scan, emit (tile id, slot) pairs in depth
 //      order, stable radix sort on the tile id only (2 passes of 8 bits), tile ranges, blend
@@ -27,11 +29,17 @@
 
 namespace gsr {
 
-constexpr uint32_t kMinFirstChunk = 1u << 20;    // instances in the first depth chunk (at least)
-constexpr int kFirstChunkDiv = 8;                // first chunk <= R / 8 ...
-constexpr int kFirstChunkPerTile = 288;          // ... and ~288 upper-bound instances per tile: the synthetic scenes' tiles all close
-                                                 // within 210-230 (cfg3 / cfg5 sweep: 208 needs a second chunk, 384 emits 35 % more)
-constexpr int kChunkGrowthLog2 = 2;              // then x4 per chunk
+// Chunk boundaries come from the frame itself.  Chunk c ends at the first depth rank where the mean optical depth per
+// slab pixel exceeds kChunkOpticalDepths x ln(1e4) x 4^c.  Where pixels take the cut-off relative to that mean is a
+// property of the blend rule, not of a scene: with splats scattered uniformly over the frame, half the pixels have
+// closed at a mean of 1.9 cut-off depths, 99 % at 3.3 and the last one at 4.0-4.3 (measured with the oracle on cfg2,
+// cfg3, a second seed and off-axis cameras: the mass counts the faint skirts below alpha = 1/255 that the blend
+// skips, hence > 1).  5 leaves a margin; regions the splats cover unevenly simply close in the next, 4x larger, chunk.
+constexpr float kCutoffOpticalDepth = 9.2103404f;   // -ln(GSR_T_CUTOFF)
+constexpr float kChunkOpticalDepths = 5.f;
+constexpr uint32_t kMinFirstChunk = 1u << 18;    // ... but no chunk smaller than this many upper-bound instances (x4 per chunk):
+                                                 // a chunk's fixed cost is worth a few hundred thousand instances
+constexpr int kChunkGrowthLog2 = 2;              // x4 per chunk
 
 GeomWS carve_geom(void *base, int P)
 {
@@ -40,7 +48,8 @@ GeomWS carve_geom(void *base, int P)
     char *b = (char *)base;
     const size_t Pn = (size_t)(P > 0 ? P : 1);
     w.records = (float4 *)(b + o); o += align_up(Pn * 48);
-    w.tiles_touched = (uint32_t *)(b + o); o += align_up(Pn * 4);
+    w.tiles_mass = (uint2 *)(b + o); o += align_up(Pn * 8);
+    w.mass_blocks = (unsigned long long *)(b + o); o += align_up(((Pn + kScanTileElems - 1) / kScanTileElems + 1) * 8);
     w.clamped = (uint8_t *)(b + o); o += align_up(Pn);
     for (int i = 0; i < 2; ++i) { w.sort_keys[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
     for (int i = 0; i < 2; ++i) { w.sort_vals[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
@@ -99,8 +108,8 @@ int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
                                           ws.radix_temp, &result, "depth_sort", debug, s)))
         return rc;
     if (result != 0) { set_error("internal: depth sort result buffer %d", result); return GSR_ERR_HIP; }
-    return launch_scan_inclusive(ws.tiles_touched, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, nullptr, nullptr, "scan_tiles",
-                                 debug, s, &ws.ctrl->overflow, ws.order);
+    return launch_scan_inclusive(nullptr, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, nullptr, nullptr, "scan_tiles",
+                                 debug, s, &ws.ctrl->overflow, ws.order, ws.tiles_mass, ws.mass_blocks);
 }
 
 // ---- chunk plan (one block of 9 waves): wave 0 finds V (first rank whose key is 0xFFFFFFFF), wave 1+c the end
@@ -126,26 +135,57 @@ __device__ __forceinline__ uint32_t wave_lower_bound(uint32_t n, Pred pred)   //
     return lo;
 }
 
-__global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int P, int n_tiles, int per_tile, const uint32_t *__restrict__ sorted_keys,
-                                                                            const uint32_t *__restrict__ offs_full, Ctrl *ctrl)
+// First depth rank (+1) at which the running optical mass exceeds `target`: the 2048-rank block from the block prefix
+// (64-ary search), then that block's ranks 64 at a time.
+__device__ __forceinline__ uint32_t wave_mass_end(int P, unsigned long long target, const uint32_t *__restrict__ order,
+                                                  const uint2 *__restrict__ mass, const unsigned long long *__restrict__ blocks)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nb = (uint32_t)((P + kScanTileElems - 1) / kScanTileElems);
+    if (blocks[nb] <= target) return (uint32_t)P;                                  // the whole frame stays below
+    const uint32_t b = wave_lower_bound(nb, [&](uint32_t i) { return blocks[i + 1] > target; });
+    unsigned long long run = blocks[b];
+    const uint32_t r0 = b * (uint32_t)kScanTileElems;
+    for (uint32_t base = r0; base < r0 + (uint32_t)kScanTileElems; base += 64u) {
+        const uint32_t r = base + lane;
+        unsigned long long inc = r < (uint32_t)P ? (unsigned long long)mass[order[r]].y : 0ull;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned long long t = __shfl_up(inc, off);
+            if ((int)lane >= off) inc += t;
+        }
+        const unsigned long long m = __ballot(run + inc > target);
+        if (m != 0ull) return min((uint32_t)P, base + (uint32_t)__ffsll((long long)m));      // include the crossing rank
+        run += __shfl(inc, 63);
+    }
+    return min((uint32_t)P, r0 + (uint32_t)kScanTileElems);
+}
+
+__global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int P, unsigned long long first_mass, const uint32_t *__restrict__ sorted_keys,
+                                                                            const uint32_t *__restrict__ offs_full,
+                                                                            const uint32_t *__restrict__ order, const uint2 *__restrict__ mass,
+                                                                            const unsigned long long *__restrict__ mass_blocks, Ctrl *ctrl)
 {
     __shared__ uint32_t sh_V, sh_end[GSR_MAX_CHUNKS];
     const uint32_t R = ctrl->R_total;
     const int w = threadIdx.x >> 6;
-    uint32_t first = (uint32_t)per_tile * (uint32_t)n_tiles;
-    if (first > R / (uint32_t)kFirstChunkDiv) first = R / (uint32_t)kFirstChunkDiv;
-    if (first < kMinFirstChunk) first = kMinFirstChunk;
     if (w == 0) {
         const uint32_t V = wave_lower_bound((uint32_t)P, [&](uint32_t i) { return sorted_keys[i] == 0xFFFFFFFFu; });
         if ((threadIdx.x & 63) == 0) sh_V = V;
     } else {
-        // invisible Gaussians have a tile count of 0, so the scan is flat beyond V: searching [0,P) and clamping
-        // to V gives the same answer as searching [0,V)
+        // invisible Gaussians have a tile count and a mass of 0, so both running sums are flat beyond V: searching
+        // [0,P) and clamping to V gives the same answer as searching [0,V)
         const int c = w - 1;
-        const uint64_t target = (uint64_t)first << (kChunkGrowthLog2 * c);
         uint32_t end = (uint32_t)P;
-        if (c < GSR_MAX_CHUNKS - 1 && target < (uint64_t)R)
-            end = wave_lower_bound((uint32_t)P, [&](uint32_t i) { return (uint64_t)offs_full[i] > target; });
+        if (c < GSR_MAX_CHUNKS - 1) {
+            end = wave_mass_end(P, first_mass << (kChunkGrowthLog2 * c), order, mass, mass_blocks);
+            const uint64_t floor_inst = (uint64_t)kMinFirstChunk << (kChunkGrowthLog2 * c);
+            if (floor_inst >= (uint64_t)R) end = (uint32_t)P;
+            else if (end < (uint32_t)P) {
+                const uint32_t e2 = wave_lower_bound((uint32_t)P, [&](uint32_t i) { return (uint64_t)offs_full[i] > floor_inst; });
+                end = max(end, e2);
+            }
+        }
         if ((threadIdx.x & 63) == 0) sh_end[c] = end;
     }
     __syncthreads();
@@ -174,7 +214,11 @@ __global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int 
 int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 {
     ProfileScope prof("chunk_plan", s);
-    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(kWave * (GSR_MAX_CHUNKS + 1)), 0, s, f.P, (f.ty1 - f.ty0) * f.Gx, kFirstChunkPerTile, ws.sort_keys[0], ws.offs_full, ws.ctrl);
+    const double slab_px = (double)(f.ty1 - f.ty0) * GSR_TILE * (double)f.Gx * GSR_TILE;
+    const unsigned long long first_mass =
+        (unsigned long long)((double)kChunkOpticalDepths * kCutoffOpticalDepth * slab_px * (double)kMassUnitsPerPixelNeper) + 1ull;
+    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(kWave * (GSR_MAX_CHUNKS + 1)), 0, s, f.P, first_mass, ws.sort_keys[0], ws.offs_full, ws.order,
+                       ws.tiles_mass, ws.mass_blocks, ws.ctrl);
     GSR_LAUNCH_CHECK("chunk_plan", debug, s);
     return GSR_OK;
 }

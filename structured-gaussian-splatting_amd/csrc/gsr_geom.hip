@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
                                                            const float *__restrict__ opac, const float *__restrict__ shs,
                                                            const float *__restrict__ shs_rest,
                                                            const float *__restrict__ colpre, float4 *__restrict__ records,
-                                                           uint32_t *__restrict__ tiles, uint8_t *__restrict__ clamped,
+                                                           uint2 *__restrict__ tiles_mass, uint8_t *__restrict__ clamped,
                                                            int32_t *__restrict__ radii, uint32_t *__restrict__ sort_keys,
                                                            uint32_t *__restrict__ sort_vals, uint32_t *__restrict__ prefilter_flag)
 {
@@ -99,7 +99,8 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
     preprocess_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.opacity, LAZY ? nullptr : in.sh(),
                         (!RAW && colpre) ? colpre + 3 * (size_t)i : nullptr, o);
     radii[i] = o.radius;
-    tiles[i] = o.tiles;
+    // mass in fixed point: integer sums are order-independent
+    tiles_mass[i] = make_uint2(o.tiles, (uint32_t)fminf(o.mass * kMassUnitsPerPixelNeper, 4294967040.f));
     clamped[i] = (uint8_t)o.clamped;
     records[3 * (size_t)i + 0] = make_float4(o.s.x, o.s.y, o.s.cA, o.s.cB);
     records[3 * (size_t)i + 1] = make_float4(o.s.cC, o.s.op, o.s.r, o.s.g);
@@ -125,7 +126,7 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 #define GSR_PRE(DEG, RAW, LAZY)                                                                                     \
     hipLaunchKernelGGL((k_preprocess<DEG, RAW, LAZY>), dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
                        cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs, g.shs_rest,   \
-                       g.colors_precomp, ws.records, ws.tiles_touched, ws.clamped, radii, ws.sort_keys[0],              \
+                       g.colors_precomp, ws.records, ws.tiles_mass, ws.clamped, radii, ws.sort_keys[0],                 \
                        ws.sort_vals[0], prefilter_flag)
     if (g.shs) {                  // colours from SH: lazily, per binned chunk
         if (g.raw) GSR_PRE(0, true, true);

@@ -78,7 +78,9 @@ struct Ctrl {                   // small device-side control block of one frame
 };
 struct GeomWS {                 // O(P): the reference's geomBuffer
     float4 *records;            // [P,3]  Splat records, by Gaussian
-    uint32_t *tiles_touched;    // [P]    by Gaussian
+    uint2 *tiles_mass;          // [P]    by Gaussian: .x = tiles touched, .y = optical mass inside the slab in 1/64 pixel-neper
+                                //        units (gsr_math.h optical_mass): one 8-byte gather in the depth-order scan
+    unsigned long long *mass_blocks;   // [ceil(P / 2048) + 1] exclusive prefix, in depth order, of the mass per 2048-rank block
     uint8_t *clamped;           // [P]    by Gaussian
     uint32_t *sort_keys[2];     // [P] x2 depth bits (0xFFFFFFFF = invisible)
     uint32_t *sort_vals[2];     // [P] x2 Gaussian index; after the sort: depth rank -> Gaussian
@@ -111,6 +113,8 @@ struct BinningWS {              // O(R): the reference's binningBuffer
     size_t total;
 };
 constexpr int kLastShift = 26;  // last_enc = (chunk + 1) << kLastShift | position
+constexpr float kMassUnitsPerPixelNeper = 64.f;   // GeomWS::mass fixed point
+constexpr int kScanTileElems = 2048;              // elements per block of the prefix sums (= granularity of mass_blocks)
 
 size_t scan_temp_bytes(int n);
 size_t radix_temp_bytes();
@@ -121,7 +125,8 @@ BinningWS carve_binning(void *base, int64_t R);
 // ---- primitives (gsr_sort.hip)
 int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
                           uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow = nullptr,
-                          const uint32_t *gather = nullptr);
+                          const uint32_t *gather = nullptr, const uint2 *aux = nullptr,
+                          unsigned long long *aux_block_prefix = nullptr);
 template <typename K>
 int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
                       const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,

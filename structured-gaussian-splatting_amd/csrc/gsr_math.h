@@ -255,8 +255,27 @@ struct PreOut {
     int radius;            // 0 = invisible
     unsigned tiles;        // tiles touched inside the slab
     unsigned clamped;      // bit c: channel c clamped at 0
+    float mass;            // optical mass inside the slab, pixel x nepers (optical_mass below); 0 when no tile is touched
     Splat s;
 };
+
+// ---- optical mass of a splat: the integral over the image plane of its optical depth tau(x) = -ln(1 - alpha(x)),
+// alpha(x) = opacity * exp(power(x)).  For a 2D Gaussian of covariance Sigma' that integral is
+// 2 pi sqrt(det Sigma') * Li2(opacity) (dilogarithm; = opacity * 2 pi sqrt(det) for faint splats).  A pixel takes the
+// blend's transmittance cut-off (T < 1e-4, A.8) once the optical depths in front of it sum to ln(1e4) = 9.21, so
+// the running sum of masses in depth order, divided by the pixel count, is the frame's mean optical depth: the
+// chunk plan (gsr_binning.hip) cuts the depth order where that mean reaches a fixed multiple of 9.21 instead of at
+// a swept instance count.  Capped by what the splat's binning rectangle can hold, scaled to the slab's share of it.
+GSR_HD float optical_mass(float det_cov2d, float opacity, int rect_tiles_full, int rect_tiles_slab)
+{
+    if (rect_tiles_full <= 0 || rect_tiles_slab <= 0) return 0.f;
+    const float op = fminf(fmaxf(opacity, 0.f), (float)GSR_ALPHA_MAX);
+    const float li2 = op * (1.f + op * (0.25f + 0.39f * op * op));             // Li2 on [0, 1] to 2 %
+    float m = 6.2831853f * sqrtf(fmaxf(det_cov2d, 0.f)) * li2;
+    const float cap = (float)rect_tiles_full * (float)(GSR_TILE * GSR_TILE) * -logf(1.f - op);
+    m = fminf(m, cap);
+    return m * ((float)rect_tiles_slab / (float)rect_tiles_full);
+}
 
 // ---- A.6: colour of one Gaussian from its [K,3] SH coefficients (+0.5, clamp at 0; bit c of `clamped` = channel c
 // clamped).  Its own function because the forward evaluates it LAZILY: only for the depth chunks that are binned.
@@ -294,7 +313,7 @@ GSR_HD void preprocess_one(const FrameK &f, const float *V, const float *PV, con
                            const float p[3], const float *scale, const float *quat, const float *covpre,
                            float opacity, const float *sh, const float *colpre, PreOut &o)
 {
-    o.radius = 0; o.tiles = 0; o.clamped = 0;
+    o.radius = 0; o.tiles = 0; o.clamped = 0; o.mass = 0.f;
     o.s = Splat{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float pv[3];
     pv[0] = p[0] * V[0] + p[1] * V[4] + p[2] * V[8] + V[12];
@@ -336,10 +355,12 @@ GSR_HD void preprocess_one(const FrameK &f, const float *V, const float *PV, con
     o.s.r = rgb[0]; o.s.g = rgb[1]; o.s.b = rgb[2];
     o.s.depth = pv[2];
     TileRect t = tight_rect(r, px, py, e.a, e.c, opacity);
+    const int full_tiles = (t.x1 - t.x0) * (t.y1 - t.y0);
     slab_clip(t, f);
     o.s.rect_x = pack_u16x2(t.x0, t.x1);
     o.s.rect_y = pack_u16x2(t.y0, t.y1);
     o.tiles = (unsigned)((t.x1 - t.x0) * (t.y1 - t.y0));
+    o.mass = optical_mass(det, opacity, full_tiles, (int)o.tiles);
 }
 
 struct GeomGrad {

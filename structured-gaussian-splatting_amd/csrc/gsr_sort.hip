@@ -18,6 +18,7 @@ namespace gsr {
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanBlock * kScanItems;      // 2048 elements per block
+static_assert(kScanTile == kScanTileElems, "mass_blocks granularity");
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
 {
@@ -48,29 +49,88 @@ __device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *sh_wav
     return inc + base;
 }
 
+// 64-bit flavour for the auxiliary (optical mass) block sums
+__device__ __forceinline__ unsigned long long block_incl_scan64(unsigned long long v, unsigned long long *sh_wave /*[4]*/,
+                                                               unsigned long long *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned long long t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) sh_wave[w] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kScanBlock / kWave; ++i) {
+        const unsigned long long s = sh_wave[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return inc + base;
+}
+
 // gather != nullptr: the scanned sequence is in[gather[i]] (tiles touched, read in depth order)
+// aux != nullptr: the input is (value, auxiliary) PAIRS and replaces `in`; the auxiliary quantity (optical mass) is summed
+// per block alongside: aux_blocks[b] = sum of aux[gather[i]].y over the block's elements (k_scan_tops turns the block
+// sums into their exclusive prefix)
 __global__ __launch_bounds__(kScanBlock) void k_scan_local(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gather,
-                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, int n)
+                                                           uint32_t *__restrict__ out, uint32_t *__restrict__ block_sums, int n,
+                                                           const uint2 *__restrict__ aux, unsigned long long *__restrict__ aux_blocks)
 {
     __shared__ uint32_t sh_wave[kScanBlock / kWave];
+    __shared__ unsigned long long sh_wave64[kScanBlock / kWave];
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     uint32_t v[kScanItems], sum = 0;
+    unsigned long long asum = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? (gather ? in[gather[base + i]] : in[base + i]) : 0u; sum += v[i]; }
+    for (int i = 0; i < kScanItems; ++i) {
+        const bool ok = base + i < n;
+        const uint32_t src = ok ? (gather ? gather[base + i] : (uint32_t)(base + i)) : 0u;
+        if (aux) {                                             // (value, auxiliary) pairs: one 8-byte gather
+            const uint2 pr = ok ? aux[src] : make_uint2(0u, 0u);
+            v[i] = pr.x; asum += pr.y;
+        } else {
+            v[i] = ok ? in[src] : 0u;
+        }
+        sum += v[i];
+    }
     uint32_t total;
     uint32_t run = block_incl_scan(sum, sh_wave, &total) - sum;
 #pragma unroll
     for (int i = 0; i < kScanItems; ++i) { run += v[i]; if (base + i < n) out[base + i] = run; }
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+    if (aux) {
+        unsigned long long atotal;
+        block_incl_scan64(asum, sh_wave64, &atotal);
+        if (threadIdx.x == 0) aux_blocks[blockIdx.x] = atotal;
+    }
 }
 
 // exclusive scan of the block sums, any count, one block
 __global__ __launch_bounds__(kScanBlock) void k_scan_tops(uint32_t *__restrict__ block_sums, int nb, uint32_t *__restrict__ grand_total,
                                                           const uint32_t *__restrict__ acc_in, uint32_t *__restrict__ acc_out,
-                                                          uint32_t *__restrict__ overflow)
+                                                          uint32_t *__restrict__ overflow, unsigned long long *__restrict__ aux_blocks)
 {
     __shared__ uint32_t sh_wave[kScanBlock / kWave];
     __shared__ unsigned long long sh_wide[kScanBlock / kWave];
+    if (aux_blocks) {                                          // block sums -> exclusive prefix, [nb] = grand total
+        unsigned long long acarry = 0;
+        for (int base = 0; base < nb; base += kScanBlock) {
+            const int i = base + threadIdx.x;
+            const unsigned long long v = i < nb ? aux_blocks[i] : 0ull;
+            unsigned long long total;
+            const unsigned long long inc = block_incl_scan64(v, sh_wide, &total);
+            if (i < nb) aux_blocks[i] = acarry + inc - v;
+            acarry += total;
+        }
+        if (threadIdx.x == 0) aux_blocks[nb] = acarry;
+        __syncthreads();
+    }
     uint32_t carry = 0;
     unsigned long long wide = 0;                               // the same sum in 64 bits, to detect wrap-around
     for (int base = 0; base < nb; base += kScanBlock) {
@@ -113,23 +173,43 @@ constexpr int kScanSmallMax = 8 * kScanTile;
 __global__ __launch_bounds__(kScanBlock) void k_scan_small(const uint32_t *__restrict__ in, const uint32_t *__restrict__ gather,
                                                            uint32_t *__restrict__ out, int n,
                                                            uint32_t *__restrict__ grand_total, const uint32_t *__restrict__ acc_in,
-                                                           uint32_t *__restrict__ acc_out, uint32_t *__restrict__ overflow)
+                                                           uint32_t *__restrict__ acc_out, uint32_t *__restrict__ overflow,
+                                                           const uint2 *__restrict__ aux, unsigned long long *__restrict__ aux_blocks)
 {
     __shared__ uint32_t sh_wave[kScanBlock / kWave];
+    __shared__ unsigned long long sh_wave64[kScanBlock / kWave];
     uint32_t carry = 0;
-    unsigned long long wide = 0;
+    unsigned long long wide = 0, acarry = 0;
     for (int t0 = 0; t0 < n; t0 += kScanTile) {
         const int base = t0 + threadIdx.x * kScanItems;
         uint32_t v[kScanItems], sum = 0;
+        unsigned long long asum = 0;
 #pragma unroll
-        for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? (gather ? in[gather[base + i]] : in[base + i]) : 0u; sum += v[i]; }
+        for (int i = 0; i < kScanItems; ++i) {
+            const bool ok = base + i < n;
+            const uint32_t src = ok ? (gather ? gather[base + i] : (uint32_t)(base + i)) : 0u;
+            if (aux) {
+                const uint2 pr = ok ? aux[src] : make_uint2(0u, 0u);
+                v[i] = pr.x; asum += pr.y;
+            } else {
+                v[i] = ok ? in[src] : 0u;
+            }
+            sum += v[i];
+        }
         uint32_t total;
         uint32_t run = carry + block_incl_scan(sum, sh_wave, &total) - sum;
 #pragma unroll
         for (int i = 0; i < kScanItems; ++i) { run += v[i]; if (base + i < n) out[base + i] = run; }
         wide += total;
         carry += total;
+        if (aux) {                                             // exclusive prefix of the per-block sums, written as we go
+            unsigned long long atotal;
+            block_incl_scan64(asum, sh_wave64, &atotal);
+            if (threadIdx.x == 0) aux_blocks[t0 / kScanTile] = acarry;
+            acarry += atotal;
+        }
     }
+    if (aux && threadIdx.x == 0) aux_blocks[(n + kScanTile - 1) / kScanTile] = acarry;
     if (threadIdx.x == 0) {
         if (grand_total) *grand_total = carry;
         if (acc_out) *acc_out = (acc_in ? *acc_in : 0u) + carry;
@@ -141,7 +221,8 @@ size_t scan_temp_bytes(int n) { return align_up((size_t)((n + kScanTile - 1) / k
 
 // out[i] = in[0] + ... + in[i]; optional *grand_total (device) = sum of all.
 int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
-                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow, const uint32_t *gather)
+                          uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow, const uint32_t *gather,
+                          const uint2 *aux, unsigned long long *aux_block_prefix)
 {
     if (n <= 0) {
         if (overflow) GSR_HIP_CHECK(hipMemsetAsync(overflow, 0, 4, s));
@@ -151,14 +232,16 @@ int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, 
     }
     ProfileScope prof(name, s);
     if (n <= kScanSmallMax) {
-        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, s, in, gather, out, n, grand_total, acc_in, acc_out, overflow);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(kScanBlock), 0, s, in, gather, out, n, grand_total, acc_in, acc_out, overflow,
+                           aux, aux_block_prefix);
         GSR_LAUNCH_CHECK(name, debug, s);
         return GSR_OK;
     }
     const int nb = (n + kScanTile - 1) / kScanTile;
     uint32_t *sums = (uint32_t *)temp;
-    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kScanBlock), 0, s, in, gather, out, sums, n);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(kScanBlock), 0, s, sums, nb, grand_total, acc_in, acc_out, overflow);
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kScanBlock), 0, s, in, gather, out, sums, n, aux, aux_block_prefix);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(kScanBlock), 0, s, sums, nb, grand_total, acc_in, acc_out, overflow,
+                       aux ? aux_block_prefix : nullptr);
     if (nb > 1) hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kScanBlock), 0, s, out, sums, n);
     GSR_LAUNCH_CHECK(name, debug, s);
     return GSR_OK;

@@ -192,7 +192,8 @@ def debug_views(desc, geom_ws, binning_ws, image_ws, plan: FramePlan) -> dict:
         return ws[off:off + nbytes].view(dtype).view(shape)
     return dict(
         splat_records=view(geom_ws, v.splat_records, P * 48, torch.float32, (P, 12)),
-        tiles_touched=view(geom_ws, v.tiles_touched, P * 4, torch.int32, (P,)),
+        tiles_touched=(lambda t: None if t is None else t[:, 0])(view(geom_ws, v.tiles_touched, P * 8, torch.int32, (P, 2))),
+        optical_mass=(lambda t: None if t is None else t[:, 1])(view(geom_ws, v.tiles_touched, P * 8, torch.int32, (P, 2))),
         depth_order=view(geom_ws, v.depth_order, P * 4, torch.int32, (P,)),
         point_offsets=view(geom_ws, v.point_offsets, P * 4, torch.int32, (P,)),
         clamped=view(geom_ws, v.clamped, P, torch.uint8, (P,)),
