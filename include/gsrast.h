@@ -42,7 +42,7 @@ typedef enum gsr_status {
 /* Per-call configuration = the scalar fields of GaussianRasterizationSettings
  * (gaussian_renderer/__init__.py:36-49) plus the tile-row slab of multi-GPU sharding. */
 typedef struct gsr_frame_desc {
-    int32_t P;               /* number of Gaussians                                              */
+    int32_t P;               /* number of Gaussians (< 2^28)                                     */
     int32_t sh_degree;       /* active SH degree D, 0..3                                          */
     int32_t sh_coeffs;       /* M = stored coefficients per channel of shs[P,M,3]; 0 with colors */
     int32_t width, height;   /* image_width, image_height                                        */
@@ -179,7 +179,8 @@ typedef struct gsr_debug_views {
     const uint32_t *depth_order;   /* [P]  depth rank -> Gaussian (invisible ones last)                   */
     const uint32_t *point_offsets; /* [P]  inclusive scan of tiles touched, in depth order               */
     const uint8_t *clamped;        /* [P]  bit c set <=> channel c clamped */
-    const uint32_t *sorted_gaussian; /* [<=R] Gaussian index per binned instance (chunks concatenated)   */
+    const uint32_t *sorted_gaussian; /* [<=R] per binned instance (chunks concatenated): Gaussian index in bits 0..27, in bits
+                                        28..31 the mask of the tile's 8x8 quadrants the splat can reach (sub-tile culling) */
     const uint32_t *ranges;        /* [GSR_MAX_CHUNKS, Tn, 2] absolute [start, end) per chunk and tile   */
     const float *final_T;          /* [H*W] (negative sign marks a pixel that hit the cut-off)           */
     const int32_t *n_contrib;      /* [H*W] encoded: (chunk + 1) << 26 | position in that chunk's range  */

@@ -79,6 +79,11 @@ static void profile_drain()
 static int validate(const gsr_frame_desc *d)
 {
     if (!d) { set_error("frame descriptor is NULL"); return GSR_ERR_INVALID_ARGUMENT; }
+    if (d->P >= (1 << kQuadMaskShift)) {
+        set_error("P = %d: at most 2^%d - 1 Gaussians per frame (the sorted instance list packs a 4-bit quadrant mask above the index)",
+                  d->P, kQuadMaskShift);
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
     if (d->P < 0 || d->width <= 0 || d->height <= 0) {
         set_error("bad frame: P=%d width=%d height=%d", d->P, d->width, d->height);
         return GSR_ERR_INVALID_ARGUMENT;

@@ -144,21 +144,41 @@ __device__ __forceinline__ uint32_t wave_mass_end(int P, unsigned long long targ
     const uint32_t nb = (uint32_t)((P + kScanTileElems - 1) / kScanTileElems);
     if (blocks[nb] <= target) return (uint32_t)P;                                  // the whole frame stays below
     const uint32_t b = wave_lower_bound(nb, [&](uint32_t i) { return blocks[i + 1] > target; });
-    unsigned long long run = blocks[b];
-    const uint32_t r0 = b * (uint32_t)kScanTileElems;
-    for (uint32_t base = r0; base < r0 + (uint32_t)kScanTileElems; base += 64u) {
-        const uint32_t r = base + lane;
-        unsigned long long inc = r < (uint32_t)P ? (unsigned long long)mass[order[r]].y : 0ull;
+    // inside the block: every lane sums 32 consecutive ranks (32 independent gathers in flight per lane: two memory
+    // latencies in all, not 64), the wave scans the 64 lane sums, and the lane that holds the crossing walks its 32 values
+    constexpr int kPerLane = kScanTileElems / kWave;
+    const uint32_t r0 = b * (uint32_t)kScanTileElems + lane * (uint32_t)kPerLane;
+    uint32_t mv[kPerLane];
+    unsigned long long mine = 0;
 #pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const unsigned long long t = __shfl_up(inc, off);
-            if ((int)lane >= off) inc += t;
-        }
-        const unsigned long long m = __ballot(run + inc > target);
-        if (m != 0ull) return min((uint32_t)P, base + (uint32_t)__ffsll((long long)m));      // include the crossing rank
-        run += __shfl(inc, 63);
+    for (int i = 0; i < kPerLane; ++i) {
+        const uint32_t r = r0 + (uint32_t)i;
+        mv[i] = r < (uint32_t)P ? mass[order[r]].y : 0u;
+        mine += mv[i];
     }
-    return min((uint32_t)P, r0 + (uint32_t)kScanTileElems);
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const unsigned long long t = __shfl_up(inc, off);
+        if ((int)lane >= off) inc += t;
+    }
+    const unsigned long long before = blocks[b] + inc - mine;                      // running mass in front of this lane's ranks
+    const unsigned long long m = __ballot(before + mine > target);
+    if (m == 0ull) return min((uint32_t)P, (b + 1u) * (uint32_t)kScanTileElems);   // cannot happen (blocks[b + 1] > target)
+    const int owner = __ffsll((long long)m) - 1;
+    uint32_t end = 0;
+    if ((int)lane == owner) {
+        unsigned long long run = before;
+        bool found = false;
+        end = r0 + (uint32_t)kPerLane;
+#pragma unroll
+        for (int i = 0; i < kPerLane; ++i) {                                       // constant indices: mv stays in registers
+            run += mv[i];
+            if (!found && run > target) { end = r0 + (uint32_t)i + 1u; found = true; }    // include the crossing rank
+        }
+    }
+    end = (uint32_t)__shfl((int)end, owner);
+    return min((uint32_t)P, end);
 }
 
 __global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int P, unsigned long long first_mass, const uint32_t *__restrict__ sorted_keys,
@@ -350,7 +370,7 @@ __global__ __launch_bounds__(W *kWave) void k_emit_team(FrameK f, int c, int r0,
     if (threadIdx.x == 0) row_begin[r] = first;
     if (cnt == 0u) return;
     const uint32_t g = order[r];
-    const float4 cc = records[3 * (size_t)g + 2];
+    const float4 ra = records[3 * (size_t)g], rb = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
     const TileRect t = unpack_rect(cc.z, cc.w);
     const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0), ns = (total + kWave - 1) >> 6;
     const uint32_t mb = mask_base(offs_full, r0, r, (uint32_t)total);
@@ -384,7 +404,9 @@ __global__ __launch_bounds__(W *kWave) void k_emit_team(FrameK f, int c, int r0,
                 const uint32_t slot = first + sh_off[q] + (uint32_t)__popcll(mq & ((1ull << lane) - 1ull));
                 keys[slot] = (uint32_t)(ty * f.Gx + tx);
                 vals[slot] = slot;
-                inst_gid[slot] = g;
+                // sub-tile culling for the blend kernels: which 8x8 quadrants of this tile the splat can reach
+                inst_gid[slot] = g | (quadrant_mask_q(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, (float)(tx * GSR_TILE), (float)(ty * GSR_TILE))
+                                      << kQuadMaskShift);
             }
         }
         carry += wtot;
@@ -502,8 +524,9 @@ __global__ __launch_bounds__(kBinBlock) void k_bin_chunk(FrameK f, int c, int r0
         const uint32_t i = k - start;
         bool want = false;
         uint32_t tile = 0;
+        int tx = 0, ty = 0;
         if (valid) {
-            const int tx = (int)(xy & 0xFFFFu) + (int)(i % w), ty = (int)(xy >> 16) + (int)(i / w);
+            tx = (int)(xy & 0xFFFFu) + (int)(i % w); ty = (int)(xy >> 16) + (int)(i / w);
             tile = (uint32_t)(ty * f.Gx + tx);
             if ((bits[ty * W64 + (tx >> 6)] >> (tx & 63)) & 1ull) {
                 float A, B, C, op;
@@ -523,7 +546,8 @@ __global__ __launch_bounds__(kBinBlock) void k_bin_chunk(FrameK f, int c, int r0
                 const uint32_t slot = sh_first[wv][j] + before + (uint32_t)__popcll(below);
                 keys[slot] = tile;
                 vals[slot] = slot;
-                inst_gid[slot] = sh_gid[wv][j];
+                inst_gid[slot] = sh_gid[wv][j] |
+                                 (quadrant_mask_q(a.x, a.y, a.z, a.w, b.x, b.y, (float)(tx * GSR_TILE), (float)(ty * GSR_TILE)) << kQuadMaskShift);
             }
         }
         __builtin_amdgcn_wave_barrier();

@@ -106,13 +106,15 @@ struct ImageWS {                // O(N + Tn): the reference's imgBuffer
 struct BinningWS {              // O(R): the reference's binningBuffer
     uint32_t *keys[2];          // [R] x2 tile id (radix double buffer)
     uint32_t *vals[2];          // [R] x2 payload = instance slot (absolute index in emission order)
-    uint32_t *inst_gid;         // [R] slot -> Gaussian
-    uint32_t *sorted_gid;       // [R] sorted position -> Gaussian
+    uint32_t *inst_gid;         // [R] slot -> Gaussian | quadrant mask << 28 (gsr_math.h quadrant_mask_q of the instance's tile)
+    uint32_t *sorted_gid;       // [R] sorted position -> the same word
     float *grad_rows;           // [instances emitted, kRowFloats] per-instance screen-space gradient rows: the caller's
                                 // backward-time allocation (gsr_backward_rows_size), not part of the carved block
     size_t total;
 };
 constexpr int kLastShift = 26;  // last_enc = (chunk + 1) << kLastShift | position
+constexpr int kQuadMaskShift = 28;                // BinningWS::inst_gid / sorted_gid = quadrant mask << 28 | Gaussian (P < 2^28)
+constexpr uint32_t kGidMask = (1u << kQuadMaskShift) - 1u;
 constexpr float kMassUnitsPerPixelNeper = 64.f;   // GeomWS::mass fixed point
 constexpr int kScanTileElems = 2048;              // elements per block of the prefix sums (= granularity of mass_blocks)
 

@@ -95,6 +95,52 @@ GSR_HD bool tile_may_contribute(float sx, float sy, float A, float B, float C, f
     return qmax >= need - (0.01f + 1e-5f * S);
 }
 
+// ---- sub-tile culling, same bound as tile_may_contribute on an arbitrary pixel rectangle [x0, x1] x [y0, y1] (pixel
+// centres, inclusive), written on the PRE-SCALED record fields (Splat): p(d) = qA dx^2 + qB dx dy + qC dy^2 + lop is
+// log2(opacity * exp(power(d))), a pixel accepts the splat iff log2(1/255) <= p and p <= lop.  Returns false only when
+// no pixel of the rectangle can accept it (margins as in tile_may_contribute, in log2 units).
+GSR_HD bool rect_may_contribute_q(float sx, float sy, float qA, float qB, float qC, float lop, float x0, float x1, float y0,
+                                  float y1)
+{
+    const float kLog2AlphaMin = -7.994353437f;                  // log2(1/255)
+    if (lop < kLog2AlphaMin) return false;
+    if (!(qA < 0.f) || !(qC < 0.f) || !(4.f * qA * qC - qB * qB > 0.f)) return true;     // not a proper ellipse: keep
+    const float dx0 = sx - x1, dx1 = sx - x0, dy0 = sy - y1, dy1 = sy - y0;         // d = splat - pixel
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;          // centre inside the rectangle
+    const float hC = -0.5f * qB / qC, hA = -0.5f * qB / qA;     // vertex of the 1-D quadratic along an edge
+    float qmax = -3.0e38f;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e < 2; ++e) {
+        const float ex = e ? dx1 : dx0;                             // edge dx = ex, dy free
+        const float dy = fminf(dy1, fmaxf(dy0, hC * ex));
+        qmax = fmaxf(qmax, (qA * ex + qB * dy) * ex + qC * dy * dy);
+        const float ey = e ? dy1 : dy0;                             // edge dy = ey, dx free
+        const float dx = fminf(dx1, fmaxf(dx0, hA * ey));
+        qmax = fmaxf(qmax, (qC * ey + qB * dx) * ey + qA * dx * dx);
+    }
+    const float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1));
+    const float S = -qA * mx * mx - qC * my * my + fabsf(qB) * mx * my;
+    return qmax >= (kLog2AlphaMin - lop) - (0.0145f + 1e-5f * S);
+}
+
+// Bit k (k = qx + 2 qy) set <=> the 8x8 quadrant (qx, qy) of the 16x16 tile whose first pixel is (px0, py0) may hold a
+// pixel that accepts the splat.  The blend kernels map one quadrant to one pixel per lane and skip clear quadrants.
+GSR_HD unsigned quadrant_mask_q(float sx, float sy, float qA, float qB, float qC, float lop, float px0, float py0)
+{
+    unsigned m = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 4; ++k) {
+        const float x0 = px0 + (float)((k & 1) * (GSR_TILE / 2)), y0 = py0 + (float)((k >> 1) * (GSR_TILE / 2));
+        if (rect_may_contribute_q(sx, sy, qA, qB, qC, lop, x0, x0 + (float)(GSR_TILE / 2 - 1), y0, y0 + (float)(GSR_TILE / 2 - 1)))
+            m |= 1u << k;
+    }
+    return m;
+}
+
 GSR_HD void slab_clip(TileRect &r, const FrameK &f)
 {
     if (r.y0 < f.ty0) r.y0 = f.ty0;

@@ -2,9 +2,10 @@
 // per-Gaussian reduction of the backward's instance rows.  Spec: SURVEY A.8 / A.9.
 //
 // MI355X mapping ("one wave, one tile"):
-//   * a 16x16 binning tile is blended by ONE wave64; lane l owns column x = l & 15 and the four rows
-//     y = (l >> 4) + 4k, k = 0..3 ("strips").  dx, A*dx^2 and B*dx are shared by a lane's four pixels,
-//     no workgroup barrier exists anywhere in the blend loop, and early termination is a wave ballot.
+//   * a 16x16 binning tile is blended by ONE wave64; lane l owns the pixel (l & 7, l >> 3) of each of the tile's
+//     four 8x8 QUADRANTS, so "can this splat reach quadrant k at all" is wave-uniform and clear quadrants are
+//     skipped with scalar branches (sub-tile culling); no workgroup barrier exists anywhere in the blend loop,
+//     and early termination is a wave ballot per quadrant.
 //   * splat records (48 B: xy, conic, opacity, rgb) are gathered 64 at a time, one per lane, staged in
 //     LDS and read back as wave-uniform broadcasts (ds_read_b128, conflict-free by construction).
 //   * backward: each lane first sums a splat's nine partial gradients over its own four pixels in
@@ -81,9 +82,41 @@ __device__ __forceinline__ float bcast_lane63(float v)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-constexpr int kStrips = 4;
-constexpr int kPairs = kStrips / 2;
-typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 operand (two pixels of one lane)
+#ifndef GSR_FWD_WAVES
+#define GSR_FWD_WAVES 5        // resident waves per SIMD the register allocation of k_render_fwd aims for
+#endif
+#ifndef GSR_BWD_WAVES
+#define GSR_BWD_WAVES 4        // ... and of k_render_bwd
+#endif
+constexpr int kQuads = 4;                                   // 8x8 quadrants of a tile: k = qx + 2 qy
+constexpr int kPairs = 2;                                   // pair p = the two quadrants of rows 8p .. 8p+7: k = 2p (left), 2p + 1 (right)
+typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 operand: the lane's two pixels of a pair
+
+// Pixel mapping ("one wave, one tile", QUADRANT-major): lane l owns the pixel (l & 7, l >> 3) of each of the tile's four
+// 8x8 quadrants.  Whether a splat can reach a quadrant at all (quadrant_mask_q: the exact alpha >= 1/255 bound on the 8x8
+// pixel rectangle) is then WAVE-UNIFORM: a batch's staging lane computes the 4-bit mask with its record, and the blend
+// loops skip clear quadrants with scalar branches.  A 2-3 px splat reaches one or two quadrants of a tile, not four.
+// The two quadrants of a pair share dy and differ by 8 in dx: when both are wanted they run as packed fp32 (v_pk_fma_f32
+// issues two FMAs in the cycles of 1.2 plain ones on gfx950: profiles/valu_microbench), otherwise the wanted one runs scalar.
+__device__ __forceinline__ int lane_px(int lane) { return lane & 7; }
+__device__ __forceinline__ int lane_py(int lane) { return lane >> 3; }
+
+// Stage up to 64 records (one per lane) of a tile's list into LDS; returns the lane's quadrant mask (bits 28..31 of the
+// sorted list's entry, put there by the emit kernels: gsr_binning.hip).
+__device__ __forceinline__ unsigned stage_batch(float4 *sh_rec, int lane, int n, const uint32_t *__restrict__ sorted_gid, uint32_t first,
+                                                const float4 *__restrict__ records)
+{
+    unsigned m = 0;
+    if (lane < n) {
+        const uint32_t v = sorted_gid[first + lane];
+        m = v >> kQuadMaskShift;
+        const float4 *r = records + 3 * (size_t)(v & kGidMask);
+        sh_rec[3 * lane + 0] = r[0];
+        sh_rec[3 * lane + 1] = r[1];
+        sh_rec[3 * lane + 2] = r[2];
+    }
+    return m;
+}
 
 // ------------------------------------------------------------------------------------------- K6
 // One launch per depth chunk.  A tile's wave resumes the pixels' state (T, colour, last contributor) where
@@ -91,7 +124,71 @@ typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 opera
 // taken the cut-off.  State lives in the image workspace: T_state (negative = done), last_enc, and the
 // un-finalised colour in out_color itself; the background term is added exactly once, when the tile
 // closes or after the last chunk.
-__global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int c, int finalize_all,
+//
+// Per pixel: Tl = live transmittance (0 once the pixel has taken the cut-off), Tf = transmittance to report (frozen at
+// the cut-off), colour, last contributor.  A rejected splat runs the same arithmetic with alpha = 0, which leaves
+// everything unchanged, so the only selects are on alpha, on the stop decision and on the contributor index.
+struct FwdPair {             // state of a lane's two pixels in one pair of quadrants (left, right)
+    v2f Tl, Tf, Cr, Cg, Cb;
+    int last0, last1;
+};
+
+template <int MODE>          // 3: both quadrants of the pair (packed), 1: the left one only, 2: the right one only
+__device__ __forceinline__ void fwd_pair(v2f lp, float lop, float cr, float cg, float cb, int contributor, FwdPair &P)
+{
+    if constexpr (MODE == 3) {
+        const float alpha0 = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(lp[0]));
+        const float alpha1 = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(lp[1]));
+        const bool keep0 = !(lp[0] > lop) && !(alpha0 < (float)GSR_ALPHA_MIN);      // power > 0  <=>  lp > lop
+        const bool keep1 = !(lp[1] > lop) && !(alpha1 < (float)GSR_ALPHA_MIN);
+        const v2f ae = {keep0 ? alpha0 : 0.f, keep1 ? alpha1 : 0.f};
+        const v2f test_T = P.Tl * (1.f - ae);                      // == Tl when rejected, 0 when already done
+        const v2f aT = ae * P.Tl;
+        const bool stop0 = test_T[0] < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
+        const bool stop1 = test_T[1] < (float)GSR_T_CUTOFF;
+        const v2f w = {stop0 ? 0.f : aT[0], stop1 ? 0.f : aT[1]};  // the stopping splat is NOT composited (A.8)
+        P.Cr += cr * w; P.Cg += cg * w; P.Cb += cb * w;
+        P.Tf = v2f{stop0 ? P.Tf[0] : test_T[0], stop1 ? P.Tf[1] : test_T[1]};
+        P.Tl = v2f{stop0 ? 0.f : test_T[0], stop1 ? 0.f : test_T[1]};
+        P.last0 = (keep0 && !stop0) ? contributor : P.last0;
+        P.last1 = (keep1 && !stop1) ? contributor : P.last1;
+    } else {
+        constexpr int e = MODE - 1;
+        const float alpha = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(lp[e]));
+        const bool keep = !(lp[e] > lop) && !(alpha < (float)GSR_ALPHA_MIN);
+        const float ae = keep ? alpha : 0.f;
+        const float test_T = P.Tl[e] * (1.f - ae);
+        const bool stop = test_T < (float)GSR_T_CUTOFF;
+        const float w = stop ? 0.f : ae * P.Tl[e];
+        P.Cr[e] += cr * w; P.Cg[e] += cg * w; P.Cb[e] += cb * w;
+        P.Tf[e] = stop ? P.Tf[e] : test_T;
+        P.Tl[e] = stop ? 0.f : test_T;
+        if constexpr (e == 0) P.last0 = (keep && !stop) ? contributor : P.last0;
+        else P.last1 = (keep && !stop) ? contributor : P.last1;
+    }
+}
+
+__device__ __forceinline__ void fwd_pair_dispatch(unsigned mp, v2f lp, float lop, float cr, float cg, float cb, int contributor, FwdPair &P)
+{
+#ifdef GSR_FWD_SINGLE
+    if (mp == 1u) { fwd_pair<1>(lp, lop, cr, cg, cb, contributor, P); return; }
+    if (mp == 2u) { fwd_pair<2>(lp, lop, cr, cg, cb, contributor, P); return; }
+#endif
+    fwd_pair<3>(lp, lop, cr, cg, cb, contributor, P);      // a clear mask bit / a dead quadrant rejects on its own (see bwd_pair_dispatch)
+}
+
+// wave-uniform 4-bit mask: quadrant k still has a live pixel
+__device__ __forceinline__ unsigned live_quadrants(const FwdPair &A, const FwdPair &B)
+{
+    unsigned m = 0;
+    if (__ballot(A.Tl[0] != 0.f) != 0ull) m |= 1u;
+    if (__ballot(A.Tl[1] != 0.f) != 0ull) m |= 2u;
+    if (__ballot(B.Tl[0] != 0.f) != 0ull) m |= 4u;
+    if (__ballot(B.Tl[1] != 0.f) != 0ull) m |= 8u;
+    return m;
+}
+
+__global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, int n_tiles, int c, int finalize_all,
                                                       const uint2 *__restrict__ ranges_c, uint32_t *__restrict__ open,
                                                       const uint32_t *__restrict__ sorted_gid,
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
@@ -105,101 +202,87 @@ __global__ __launch_bounds__(kWave) void k_render_fwd(FrameK f, int n_tiles, int
     if (open[tile] == 0u) return;                       // closed by an earlier chunk: pixels are final
     const uint2 rng = ranges_c[tile];
     const int lane = threadIdx.x;
-    const int px = tx * GSR_TILE + (lane & 15);
-    const int py0 = ty * GSR_TILE + (lane >> 4);
-    const float fx = (float)px;
+    const int px0 = tx * GSR_TILE + lane_px(lane), py0 = ty * GSR_TILE + lane_py(lane);       // the lane's pixel in quadrant 0
+    const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 8.f;
     const size_t N = (size_t)f.W * f.H;
 
-    // Per pixel: Tl = live transmittance (0 once the pixel has taken the cut-off), Tf = transmittance to report
-    // (frozen at the cut-off), colour, last contributor.  A rejected splat runs the same arithmetic with
-    // alpha = 0, which leaves everything unchanged, so the only selects are on alpha, on the stop decision and
-    // on the contributor index.
-    float fy[kStrips], Tl[kStrips], Tf[kStrips], Cr[kStrips], Cg[kStrips], Cb[kStrips];
-    int last[kStrips];
-#pragma unroll
-    for (int k = 0; k < kStrips; ++k) {
-        const int py = py0 + 4 * k;
-        fy[k] = (float)py;
+    FwdPair P0, P1;
+    auto load_px = [&](int k, float &tf, float &tl, float &r_, float &g_, float &b_, int &last) {
+        const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
         const bool inside = px < f.W && py < f.H;
-        Tf[k] = 1.f; Cr[k] = Cg[k] = Cb[k] = 0.f; last[k] = 0;
-        Tl[k] = inside ? 1.f : 0.f;
+        tf = 1.f; tl = inside ? 1.f : 0.f; r_ = g_ = b_ = 0.f; last = 0;
         if (c > 0 && inside) {
             const size_t pix = (size_t)py * f.W + px;
             const float ts = T_state[pix];
-            Tf[k] = fabsf(ts);
-            Tl[k] = ts < 0.f ? 0.f : ts;
-            Cr[k] = out_color[pix]; Cg[k] = out_color[N + pix]; Cb[k] = out_color[2 * N + pix];
-            last[k] = last_enc[pix];
+            tf = fabsf(ts);
+            tl = ts < 0.f ? 0.f : ts;
+            r_ = out_color[pix]; g_ = out_color[N + pix]; b_ = out_color[2 * N + pix];
+            last = last_enc[pix];
         }
+    };
+    {
+        float tf0, tl0, r0, g0, b0, tf1, tl1, r1, g1, b1;
+        load_px(0, tf0, tl0, r0, g0, b0, P0.last0); load_px(1, tf1, tl1, r1, g1, b1, P0.last1);
+        P0.Tf = v2f{tf0, tf1}; P0.Tl = v2f{tl0, tl1}; P0.Cr = v2f{r0, r1}; P0.Cg = v2f{g0, g1}; P0.Cb = v2f{b0, b1};
+        load_px(2, tf0, tl0, r0, g0, b0, P1.last0); load_px(3, tf1, tl1, r1, g1, b1, P1.last1);
+        P1.Tf = v2f{tf0, tf1}; P1.Tl = v2f{tl0, tl1}; P1.Cr = v2f{r0, r1}; P1.Cg = v2f{g0, g1}; P1.Cb = v2f{b0, b1};
     }
 
     const int n_total = (int)(rng.y - rng.x);
     const int enc_base = (c + 1) << kLastShift;
     for (int base = 0; base < n_total; base += kWave) {
-        const bool any_live = (Tl[0] != 0.f) || (Tl[1] != 0.f) || (Tl[2] != 0.f) || (Tl[3] != 0.f);
-        if (__ballot(any_live) == 0ull) break;
+        unsigned live = live_quadrants(P0, P1);
+        if (live == 0u) break;
         const int n = min(kWave, n_total - base);
         __syncthreads();
-        if (lane < n) {
-            const uint32_t gid = sorted_gid[rng.x + base + lane];
-            const float4 *r = records + 3 * (size_t)gid;
-            sh_rec[3 * lane + 0] = r[0];
-            sh_rec[3 * lane + 1] = r[1];
-            sh_rec[3 * lane + 2] = r[2];
-        }
+        const unsigned mymask = stage_batch(sh_rec, lane, n, sorted_gid, rng.x + base, records);
         __syncthreads();
-        // Strip pairs (rows 0-7 and 8-15 of the tile) whose 128 pixels have all taken the cut-off are skipped for
-        // the whole batch: a wave-uniform flag per pair, evaluated once per 64 splats.
-        bool pair_live0 = __ballot((Tl[0] != 0.f) || (Tl[1] != 0.f)) != 0ull;
-        bool pair_live1 = __ballot((Tl[2] != 0.f) || (Tl[3] != 0.f)) != 0ull;
-        for (int j = 0; j < n; ++j) {
-            if ((j & 7) == 0 && j) {            // every 8 splats: a tile that saturates mid-batch stops there, not 30 splats later
-                pair_live0 = pair_live0 && __ballot((Tl[0] != 0.f) || (Tl[1] != 0.f)) != 0ull;
-                pair_live1 = pair_live1 && __ballot((Tl[2] != 0.f) || (Tl[3] != 0.f)) != 0ull;
-                if (!pair_live0 && !pair_live1) break;
-            }
+        // splats of the batch that can reach a live quadrant, front to back (bit j = splat j): the others cost nothing
+        unsigned long long act = __ballot((mymask & live) != 0u);
+        int since_refresh = 0;
+        while (act != 0ull) {
+            const int j = __ffsll((long long)act) - 1;
+            act &= act - 1ull;
+            const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mymask, j) & live;
             const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
-            const float cb = sh_rec[3 * j + 2].x;
-            const float dx = a.x - fx;
-            const float axx = a.z * dx * dx + b.y, bx = a.w * dx;         // record is pre-scaled: p = log2(op exp(power))
+            const float cbl = sh_rec[3 * j + 2].x;
             const int contributor = enc_base | (base + j + 1);
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                if (!(p == 0 ? pair_live0 : pair_live1)) continue;
-#pragma unroll
-                for (int k = 2 * p; k < 2 * p + 2; ++k) {
-                    const float dy = a.y - fy[k];
-                    const float lp = (b.x * dy + bx) * dy + axx;
-                    const float alpha = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(lp));
-                    const bool keep = !(lp > b.y) && !(alpha < (float)GSR_ALPHA_MIN);       // power > 0  <=>  lp > lop
-                    const float ae = keep ? alpha : 0.f;
-                    const float test_T = Tl[k] * (1.f - ae);              // == Tl when rejected, 0 when already done
-                    const bool stop = test_T < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
-                    const float w = stop ? 0.f : ae * Tl[k];               // the stopping splat is NOT composited (A.8)
-                    Cr[k] += b.z * w; Cg[k] += b.w * w; Cb[k] += cb * w;
-                    Tf[k] = stop ? Tf[k] : test_T;
-                    Tl[k] = stop ? 0.f : test_T;
-                    last[k] = (keep && !stop) ? contributor : last[k];
-                }
+            const float dxl = a.x - fx0;
+            const v2f dx = {dxl, dxl - 8.f};
+            const v2f axx = a.z * dx * dx + b.y, bx = a.w * dx;       // record is pre-scaled: lp = log2(op exp(power))
+            if (m & 3u) {
+                const float dy = a.y - fy0;
+                fwd_pair_dispatch(m & 3u, (b.x * dy + bx) * dy + axx, b.y, b.z, b.w, cbl, contributor, P0);
+            }
+            if (m & 12u) {
+                const float dy = a.y - fy1;
+                fwd_pair_dispatch(m >> 2, (b.x * dy + bx) * dy + axx, b.y, b.z, b.w, cbl, contributor, P1);
+            }
+            if (++since_refresh == 8) {       // every 8 blended splats: quadrants (and tiles) that saturate mid-batch stop there
+                since_refresh = 0;
+                live = live_quadrants(P0, P1);
+                act &= __ballot((mymask & live) != 0u);
             }
         }
     }
-    const bool any_live = (Tl[0] != 0.f) || (Tl[1] != 0.f) || (Tl[2] != 0.f) || (Tl[3] != 0.f);
-    const bool closing = __ballot(any_live) == 0ull;
+    const bool closing = live_quadrants(P0, P1) == 0u;
     const bool finalize = closing || finalize_all != 0;
     const float bg0 = finalize ? bg[0] : 0.f, bg1 = finalize ? bg[1] : 0.f, bg2 = finalize ? bg[2] : 0.f;
-#pragma unroll
-    for (int k = 0; k < kStrips; ++k) {
-        const int py = py0 + 4 * k;
+    auto store_px = [&](int k, float tf, float tl, float r_, float g_, float b_, int last) {
+        const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
-            out_color[pix] = Cr[k] + Tf[k] * bg0;
-            out_color[N + pix] = Cg[k] + Tf[k] * bg1;
-            out_color[2 * N + pix] = Cb[k] + Tf[k] * bg2;
-            T_state[pix] = Tl[k] == 0.f ? -Tf[k] : Tf[k];
-            last_enc[pix] = last[k];
+            out_color[pix] = r_ + tf * bg0;
+            out_color[N + pix] = g_ + tf * bg1;
+            out_color[2 * N + pix] = b_ + tf * bg2;
+            T_state[pix] = tl == 0.f ? -tf : tf;
+            last_enc[pix] = last;
         }
-    }
+    };
+    store_px(0, P0.Tf[0], P0.Tl[0], P0.Cr[0], P0.Cg[0], P0.Cb[0], P0.last0);
+    store_px(1, P0.Tf[1], P0.Tl[1], P0.Cr[1], P0.Cg[1], P0.Cb[1], P0.last1);
+    store_px(2, P1.Tf[0], P1.Tl[0], P1.Cr[0], P1.Cg[0], P1.Cb[0], P1.last0);
+    store_px(3, P1.Tf[1], P1.Tl[1], P1.Cr[1], P1.Cg[1], P1.Cb[1], P1.last1);
     if (lane == 0) open[tile] = closing ? 0u : 1u;
 }
 
@@ -221,7 +304,103 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
 // One launch for the whole frame: a tile's wave walks its chunks last to first, each chunk's range back to
 // front.  A pixel takes part in chunk c up to its own last contributor (all of the range for chunks before
 // the one that holds it, nothing after).
-__global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
+//
+// Per pixel and splat (A.9), written so that a rejected pixel runs the same arithmetic with alpha = 0 and G = 0: T,
+// the colour behind and every partial sum then stay exactly unchanged, and only alpha and G need a select.
+//
+// Algebra: with ga = opacity * G (the alpha before its 0.99 clamp; 0 where the pixel rejects the splat) every term of A.9
+// that carries G * dL/dG = G * opacity * dL/dalpha is dL/dalpha * ga, so neither the opacity nor its reciprocal is needed
+// per pixel (dL/dopacity = sum(G dL/dalpha) = sum(ga dL/dalpha) / opacity: one division per splat, after the reduction), and
+// the conic enters through the pre-scaled record fields directly: cA = -2 ln2 qA, cB = -ln2 qB, cC = -2 ln2 qC, so
+// -(tx cA + ty cB) = ln2 (2 qA tx + qB ty): the factor ln2 goes into the row store.
+struct BwdSplat {            // wave-uniform per-splat values
+    float lop, cr, cg, cb, qA2, qB, qC2;       // qA2 = 2 qA, qC2 = 2 qC
+};
+struct BwdPair {             // state of a lane's two pixels in one pair of quadrants (left, right)
+    v2f T, bgterm, dpr, dpg, dpb;      // transmittance behind the current splat, -T_final <bg, dL/dpix>, dL/dpix
+    v2f ar, ag, ab;                    // colour behind the current splat
+    int limit0, limit1;                // contributors of the current chunk each pixel takes part in
+};
+struct BwdAcc { v2f S0, S1, S2, S3, S4, S5, S6, S7, S8; };     // the lane's nine partial sums of one splat, per pair element
+
+template <int MODE>          // 3: both quadrants of the pair (packed), 1: the left one only, 2: the right one only
+__device__ __forceinline__ bool bwd_pair(const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
+{
+    if constexpr (MODE == 3) {
+        const float araw0 = __builtin_amdgcn_exp2f(lp[0]), araw1 = __builtin_amdgcn_exp2f(lp[1]);      // = opacity * G
+        const float alpha0 = fminf((float)GSR_ALPHA_MAX, araw0), alpha1 = fminf((float)GSR_ALPHA_MAX, araw1);
+        const bool valid0 = (pos < P.limit0) && !(lp[0] > sp.lop) && !(alpha0 < (float)GSR_ALPHA_MIN);      // power > 0 <=> lp > lop
+        const bool valid1 = (pos < P.limit1) && !(lp[1] > sp.lop) && !(alpha1 < (float)GSR_ALPHA_MIN);
+        const v2f ae = {valid0 ? alpha0 : 0.f, valid1 ? alpha1 : 0.f};
+        const v2f ga = {valid0 ? araw0 : 0.f, valid1 ? araw1 : 0.f};
+        const v2f one_m = 1.f - ae;
+        const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
+        const v2f Tn_ = P.T * inv1ma;                         // T before this splat
+        const v2f w = ae * Tn_;                               // d colour / d rgb
+        // colour behind this splat (A.9's accum_rec), updated as soon as the splat is processed: B <- alpha c + (1 - alpha) B
+        const v2f dr = sp.cr - P.ar, dg = sp.cg - P.ag, db = sp.cb - P.ab;
+        v2f dL_dalpha = dr * P.dpr + dg * P.dpg + db * P.dpb;
+        P.ar += ae * dr; P.ag += ae * dg; P.ab += ae * db;
+        dL_dalpha = dL_dalpha * Tn_ + P.bgterm * inv1ma;
+        const v2f tA = dL_dalpha * ga;
+        const v2f tx = tA * dx, ty = tA * dy;
+        A.S0 += sp.qA2 * tx + sp.qB * ty;
+        A.S1 += sp.qC2 * ty + sp.qB * tx;
+        A.S2 += tx * dx;
+        A.S3 += tx * dy;
+        A.S4 += ty * dy;
+        A.S5 += tA;
+        A.S6 += w * P.dpr; A.S7 += w * P.dpg; A.S8 += w * P.dpb;
+        P.T = Tn_;
+        return valid0 || valid1;
+    } else {
+        constexpr int e = MODE - 1;
+        const float araw = __builtin_amdgcn_exp2f(lp[e]);
+        const float alpha = fminf((float)GSR_ALPHA_MAX, araw);
+        const bool valid = (pos < (e ? P.limit1 : P.limit0)) && !(lp[e] > sp.lop) && !(alpha < (float)GSR_ALPHA_MIN);
+        const float ae = valid ? alpha : 0.f;
+        const float ga = valid ? araw : 0.f;
+        const float inv1ma = fast_rcp(1.f - ae);
+        const float Tn_ = P.T[e] * inv1ma;
+        const float w = ae * Tn_;
+        const float dr = sp.cr - P.ar[e], dg = sp.cg - P.ag[e], db = sp.cb - P.ab[e];
+        float dL_dalpha = dr * P.dpr[e] + dg * P.dpg[e] + db * P.dpb[e];
+        P.ar[e] += ae * dr; P.ag[e] += ae * dg; P.ab[e] += ae * db;
+        dL_dalpha = dL_dalpha * Tn_ + P.bgterm[e] * inv1ma;
+        const float tA = dL_dalpha * ga;
+        const float tx = tA * dx[e], ty = tA * dy;
+        A.S0[e] += sp.qA2 * tx + sp.qB * ty;
+        A.S1[e] += sp.qC2 * ty + sp.qB * tx;
+        A.S2[e] += tx * dx[e];
+        A.S3[e] += tx * dy;
+        A.S4[e] += ty * dy;
+        A.S5[e] += tA;
+        A.S6[e] += w * P.dpr[e]; A.S7[e] += w * P.dpg[e]; A.S8[e] += w * P.dpb[e];
+        P.T[e] = Tn_;
+        return valid;
+    }
+}
+
+// A pair runs packed whenever either of its quadrants is wanted: a clear mask bit means that no pixel of that quadrant
+// accepts the splat, so its lanes of the packed arithmetic find `valid` false on their own.  (Scalar variants for a
+// single wanted quadrant, GSR_BWD_SINGLE, cost more in register moves and occupancy than they save: DESIGN section 7.)
+__device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
+{
+#ifdef GSR_BWD_SINGLE
+    if (mp == 1u) return bwd_pair<1>(sp, lp, dx, dy, pos, P, A);
+    if (mp == 2u) return bwd_pair<2>(sp, lp, dx, dy, pos, P, A);
+#endif
+    return bwd_pair<3>(sp, lp, dx, dy, pos, P, A);
+}
+
+__device__ __forceinline__ int wave_max_uniform(int v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
                                                       const uint32_t *__restrict__ sorted_gid,
                                                       const uint32_t *__restrict__ sorted_slot,
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
@@ -234,49 +413,46 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
     const int tile = ty * f.Gx + tx;
     const size_t Tn = (size_t)f.Gx * f.Gy;
     const int lane = threadIdx.x;
-    const int px = tx * GSR_TILE + (lane & 15);
-    const int py0 = ty * GSR_TILE + (lane >> 4);
-    const float fx = (float)px;
+    const int px0 = tx * GSR_TILE + lane_px(lane), py0 = ty * GSR_TILE + lane_py(lane);
+    const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 8.f;
     const size_t N = (size_t)f.W * f.H;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-    // Per-pixel state in PAIRS of strips (k = 2p, 2p + 1) as 2-vectors: the arithmetic below then compiles to packed
-    // fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), two pixels per VALU issue.
-    v2f fy[kPairs], T[kPairs], bgterm[kPairs], dpr[kPairs], dpg[kPairs], dpb[kPairs];
-    v2f ar[kPairs], ag[kPairs], ab[kPairs];                    // colour behind the current splat, per pixel
-    int c_last[kStrips], n_last[kStrips];
-#pragma unroll
-    for (int k = 0; k < kStrips; ++k) {
-        const int py = py0 + 4 * k;
+    // Per-pixel state in PAIRS (the left and right quadrant of a tile half) as 2-vectors: when both quadrants are wanted
+    // the arithmetic compiles to packed fp32 instructions, two pixels per VALU issue.
+    BwdPair P0, P1;
+    int c_last[kQuads], n_last[kQuads];
+    auto load_px = [&](int k, float &Tk, float &bt, float &r_, float &g_, float &b_) {
+        const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
         const bool inside = px < f.W && py < f.H;
         const size_t pix = inside ? (size_t)py * f.W + px : 0;
-        const float Tk = inside ? fabsf(T_state[pix]) : 0.f;
+        Tk = inside ? fabsf(T_state[pix]) : 0.f;
         const int enc = inside ? last_enc[pix] : 0;
         c_last[k] = (enc >> kLastShift) - 1;                              // -1: no contributor at all
         n_last[k] = enc & ((1 << kLastShift) - 1);
-        const float r_ = inside ? dL_dpix[pix] : 0.f, g_ = inside ? dL_dpix[N + pix] : 0.f, b_ = inside ? dL_dpix[2 * N + pix] : 0.f;
-        fy[k >> 1][k & 1] = (float)py;
-        T[k >> 1][k & 1] = Tk;
-        dpr[k >> 1][k & 1] = r_; dpg[k >> 1][k & 1] = g_; dpb[k >> 1][k & 1] = b_;
-        bgterm[k >> 1][k & 1] = -Tk * (bg0 * r_ + bg1 * g_ + bg2 * b_);     // -T_final * <bg, dL/dpix>
+        r_ = inside ? dL_dpix[pix] : 0.f; g_ = inside ? dL_dpix[N + pix] : 0.f; b_ = inside ? dL_dpix[2 * N + pix] : 0.f;
+        bt = -Tk * (bg0 * r_ + bg1 * g_ + bg2 * b_);                       // -T_final * <bg, dL/dpix>
+    };
+    {
+        float Ta, ba, ra, ga, bla, Tb, bb, rb, gb, blb;
+        load_px(0, Ta, ba, ra, ga, bla); load_px(1, Tb, bb, rb, gb, blb);
+        P0.T = v2f{Ta, Tb}; P0.bgterm = v2f{ba, bb}; P0.dpr = v2f{ra, rb}; P0.dpg = v2f{ga, gb}; P0.dpb = v2f{bla, blb};
+        load_px(2, Ta, ba, ra, ga, bla); load_px(3, Tb, bb, rb, gb, blb);
+        P1.T = v2f{Ta, Tb}; P1.bgterm = v2f{ba, bb}; P1.dpr = v2f{ra, rb}; P1.dpg = v2f{ga, gb}; P1.dpb = v2f{bla, blb};
     }
-#pragma unroll
-    for (int p = 0; p < kPairs; ++p) { ar[p] = v2f{0.f, 0.f}; ag[p] = ar[p]; ab[p] = ar[p]; }
+    P0.ar = P0.ag = P0.ab = P1.ar = P1.ag = P1.ab = v2f{0.f, 0.f};
     const float half_w = 0.5f * (float)f.W, half_h = 0.5f * (float)f.H;
 
     for (int c = chunks_run - 1; c >= 0; --c) {
         const uint2 rng = ranges[(size_t)c * Tn + tile];
         const int n_total = (int)(rng.y - rng.x);
         if (n_total == 0) continue;
-        int limit[kStrips];
-        int max_contrib = 0;
-#pragma unroll
-        for (int k = 0; k < kStrips; ++k) {
-            limit[k] = c < c_last[k] ? n_total : (c == c_last[k] ? n_last[k] : 0);
-            max_contrib = max(max_contrib, limit[k]);
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) max_contrib = max(max_contrib, __shfl_xor(max_contrib, off));
+        // per pixel: contributors of this chunk it takes part in; per quadrant: the wave's maximum
+        auto lim = [&](int k) { return c < c_last[k] ? n_total : (c == c_last[k] ? n_last[k] : 0); };
+        P0.limit0 = lim(0); P0.limit1 = lim(1); P1.limit0 = lim(2); P1.limit1 = lim(3);
+        const int qmax0 = wave_max_uniform(P0.limit0), qmax1 = wave_max_uniform(P0.limit1), qmax2 = wave_max_uniform(P1.limit0),
+                  qmax3 = wave_max_uniform(P1.limit1);
+        const int max_contrib = max(max(qmax0, qmax1), max(qmax2, qmax3));
 
         const int n_batches = (n_total + kWave - 1) / kWave;
         for (int bi = n_batches - 1; bi >= 0; --bi) {
@@ -287,76 +463,50 @@ __global__ __launch_bounds__(kWave, 4) void k_render_bwd(FrameK f, int n_tiles, 
             unsigned long long written = 0ull;                 // wave-uniform: bit j = splat j's row stored
             if (base < max_contrib) {
                 __syncthreads();
-                if (lane < n) {
-                    const uint32_t gid = sorted_gid[rng.x + base + lane];
-                    const float4 *r = records + 3 * (size_t)gid;
-                    sh_rec[3 * lane + 0] = r[0];
-                    sh_rec[3 * lane + 1] = r[1];
-                    sh_rec[3 * lane + 2] = r[2];
-                }
+                unsigned mymask = stage_batch(sh_rec, lane, n, sorted_gid, rng.x + base, records);
                 __syncthreads();
-                for (int j = n - 1; j >= 0; --j) {
-                    const int pos = base + j;                 // contributor index of this splat is pos + 1
-                    if (pos >= max_contrib) continue;         // wave-uniform
+                // quadrants whose pixels all stopped before a splat take no part in it (contributor index = pos + 1)
+                const int mypos = base + lane;
+                mymask &= (mypos < qmax0 ? 1u : 0u) | (mypos < qmax1 ? 2u : 0u) | (mypos < qmax2 ? 4u : 0u) | (mypos < qmax3 ? 8u : 0u);
+                unsigned long long act = __ballot(mymask != 0u);       // splats with work, walked back to front
+                while (act != 0ull) {
+                    const int j = 63 - __builtin_clzll(act);
+                    act &= ~(1ull << j);
+                    const int pos = base + j;
+                    const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mymask, j);
                     const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
-                    const float cb = sh_rec[3 * j + 2].x;
-                    const float dx = a.x - fx;
-                    const float axx = a.z * dx * dx + b.y, bx = a.w * dx;       // pre-scaled record: lp = log2(op exp(power))
-                    float cA, cB, cC, opac;                                      // the unscaled conic / opacity (per splat)
-                    unscale_conic(a.z, a.w, b.x, b.y, cA, cB, cC, opac);
-                    const float inv_op = fast_rcp(opac);
-                    v2f S0 = {0.f, 0.f}, S1 = S0, S2 = S0, S3 = S0, S4 = S0, S5 = S0, S6 = S0, S7 = S0, S8 = S0;
+                    BwdSplat sp;
+                    sp.lop = b.y; sp.cr = b.z; sp.cg = b.w; sp.cb = sh_rec[3 * j + 2].x;
+                    sp.qA2 = 2.f * a.z; sp.qB = a.w; sp.qC2 = 2.f * b.x;
+                    const float dxl = a.x - fx0;
+                    const v2f dx = {dxl, dxl - 8.f};
+                    const v2f axx = a.z * dx * dx + b.y, bx = a.w * dx;       // pre-scaled record: lp = log2(op exp(power))
+                    BwdAcc A;
+                    A.S0 = A.S1 = A.S2 = A.S3 = A.S4 = A.S5 = A.S6 = A.S7 = A.S8 = v2f{0.f, 0.f};
                     bool any_valid = false;
-#pragma unroll
-                    for (int p = 0; p < kPairs; ++p) {
-                        const v2f dy = a.y - fy[p];
-                        const v2f lp = (b.x * dy + bx) * dy + axx;
-                        v2f araw, ae, Ge;
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int k = 2 * p + e;
-                            araw[e] = __builtin_amdgcn_exp2f(fminf(lp[e], b.y));     // = op * G; power > 0 lanes are rejected
-                            const float alpha = fminf((float)GSR_ALPHA_MAX, araw[e]);
-                            const bool valid = (pos < limit[k]) && !(lp[e] > b.y) && !(alpha < (float)GSR_ALPHA_MIN);
-                            any_valid = any_valid || valid;
-                            // Rejected pixels run the same arithmetic with alpha = 0 and G = 0: T, the colour behind and
-                            // every partial sum then stay exactly unchanged, so only these two values need a select.
-                            ae[e] = valid ? alpha : 0.f;
-                            Ge[e] = valid ? araw[e] * inv_op : 0.f;
-                        }
-                        const v2f one_m = 1.f - ae;
-                        const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
-                        const v2f Tn_ = T[p] * inv1ma;                        // T before this splat
-                        const v2f w = ae * Tn_;                               // d colour / d rgb
-                        // colour behind this splat (A.9's accum_rec), updated as soon as the splat is processed:
-                        // B <- alpha c + (1 - alpha) B
-                        const v2f dr = b.z - ar[p], dg = b.w - ag[p], db = cb - ab[p];
-                        v2f dL_dalpha = dr * dpr[p] + dg * dpg[p] + db * dpb[p];
-                        ar[p] += ae * dr; ag[p] += ae * dg; ab[p] += ae * db;
-                        dL_dalpha = dL_dalpha * Tn_ + bgterm[p] * inv1ma;
-                        const v2f gdx = Ge * dx, gdy = Ge * dy;
-                        const v2f tG = opac * dL_dalpha;                      // dL/dG (times G through gdx, gdy)
-                        const v2f tx = tG * gdx, ty = tG * gdy;
-                        S0 -= tx * cA + ty * cB;                              // dL/dG * dG/ddelx
-                        S1 -= ty * cC + tx * cB;
-                        S2 += tx * dx;
-                        S3 += tx * dy;
-                        S4 += ty * dy;
-                        S5 += Ge * dL_dalpha;
-                        S6 += w * dpr[p]; S7 += w * dpg[p]; S8 += w * dpb[p];
-                        T[p] = Tn_;
+                    if (m & 3u) {
+                        const float dy = a.y - fy0;
+                        any_valid = bwd_pair_dispatch(m & 3u, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P0, A);
                     }
-                    float s0 = S0[0] + S0[1], s1 = S1[0] + S1[1], s2 = S2[0] + S2[1], s3 = S3[0] + S3[1], s4 = S4[0] + S4[1],
-                          s5 = S5[0] + S5[1], s6 = S6[0] + S6[1], s7 = S7[0] + S7[1], s8 = S8[0] + S8[1];
-                    if (__ballot(any_valid) == 0ull) continue;               // nobody accepted this splat: row stays 0
+                    if (m & 12u) {
+                        const float dy = a.y - fy1;
+                        const bool v = bwd_pair_dispatch(m >> 2, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P1, A);
+                        any_valid = any_valid || v;
+                    }
+                    if (__ballot(any_valid) == 0ull) continue;                  // nobody accepted this splat: row stays 0
+                    float s0 = A.S0[0] + A.S0[1], s1 = A.S1[0] + A.S1[1], s2 = A.S2[0] + A.S2[1], s3 = A.S3[0] + A.S3[1],
+                          s4 = A.S4[0] + A.S4[1], s5 = A.S5[0] + A.S5[1], s6 = A.S6[0] + A.S6[1], s7 = A.S7[0] + A.S7[1],
+                          s8 = A.S8[0] + A.S8[1];
                     wave_sum9_to_lane63(s0, s1, s2, s3, s4, s5, s6, s7, s8);
                     // lane 63 holds the nine totals: it stores the splat's row itself (three 16-B stores)
                     const uint32_t slot_j = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
                     written |= 1ull << j;
                     if (lane == kWave - 1) {
+                        const float inv_op = __builtin_amdgcn_exp2f(-sp.lop);              // 1 / opacity
                         float4 *row = grad_rows + 3 * (size_t)slot_j;
-                        row[0] = make_float4(s0 * half_w, s1 * half_h, s2 * -0.5f, s3 * -0.5f);
-                        row[1] = make_float4(s4 * -0.5f, s5, s6, s7);
+                        // -(tx cA + ty cB) = ln2 (2 qA tx + qB ty), likewise for y; gA, gB, gC carry the -1/2 of A.9
+                        row[0] = make_float4(s0 * (0.69314718f * half_w), s1 * (0.69314718f * half_h), s2 * -0.5f, s3 * -0.5f);
+                        row[1] = make_float4(s4 * -0.5f, s5 * inv_op, s6, s7);
                         row[2] = make_float4(s8, 0.f, 0.f, 0.f);
                     }
                 }

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libgsrast.so")
+_LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_PKG_ROOT, "lib", "libgsrast.so")      # override: kernel-variant experiments
 _CSRC = os.path.join(_PKG_ROOT, "csrc")
 SCREEN_GRAD_STRIDE = 12
 
@@ -197,7 +197,9 @@ def debug_views(desc, geom_ws, binning_ws, image_ws, plan: FramePlan) -> dict:
         depth_order=view(geom_ws, v.depth_order, P * 4, torch.int32, (P,)),
         point_offsets=view(geom_ws, v.point_offsets, P * 4, torch.int32, (P,)),
         clamped=view(geom_ws, v.clamped, P, torch.uint8, (P,)),
-        sorted_gaussian=view(binning_ws, v.sorted_gaussian, R * 4, torch.int32, (R,)),
+        # bits 0..27 Gaussian index, bits 28..31 quadrant mask (copies: the workspace word holds both)
+        sorted_gaussian=(lambda t: None if t is None else t & 0x0FFFFFFF)(view(binning_ws, v.sorted_gaussian, R * 4, torch.int32, (R,))),
+        sorted_quadrants=(lambda t: None if t is None else (t >> 28) & 0xF)(view(binning_ws, v.sorted_gaussian, R * 4, torch.int32, (R,))),
         ranges=view(image_ws, v.ranges, MAX_CHUNKS * Tn * 8, torch.int32, (MAX_CHUNKS, Tn, 2)),
         final_T=view(image_ws, v.final_T, N * 4, torch.float32, (desc.height, desc.width)),
         n_contrib=view(image_ws, v.n_contrib, N * 4, torch.int32, (desc.height, desc.width)))

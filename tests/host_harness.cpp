@@ -66,6 +66,15 @@ extern "C" void hh_tile_may_contribute(int n, const float *sx, const float *sy, 
     for (int i = 0; i < n; ++i) out[i] = tile_may_contribute(sx[i], sy[i], A[i], B[i], C[i], op[i], tx[i], ty[i]) ? 1 : 0;
 }
 
+// sub-tile culling on the pre-scaled record: 4-bit quadrant mask per (splat, tile)
+extern "C" void hh_quadrant_mask(int n, const float *rec12, const int32_t *tx, const int32_t *ty, uint8_t *out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float *r = rec12 + 12 * (size_t)i;
+        out[i] = (uint8_t)quadrant_mask_q(r[0], r[1], r[2], r[3], r[4], r[5], (float)(tx[i] * GSR_TILE), (float)(ty[i] * GSR_TILE));
+    }
+}
+
 // a14: activations of the raw parameters and their chain rule (gsr_math.h activate_raw / activate_raw_backward).
 // in: log_scales[n,3], raw_q[n,4], logits[n]; upstream d_scale[n,3], d_q[n,4], d_op[n]
 // out: scale[n,3], q[n,4], op[n] and the gradients w.r.t. the raw values in g_ls[n,3], g_rq[n,4], g_logit[n]

@@ -162,6 +162,44 @@ def test_tile_culling_is_conservative(hh):
         assert not accept.any(), f"{accept.any((1, 2)).sum()} culled instances have an accepting pixel"
 
 
+def test_quadrant_culling_is_conservative(hh):
+    """csrc/gsr_math.h quadrant_mask_q() (sub-tile culling of the blend kernels, on the pre-scaled splat record): a clear bit
+    means that NO pixel of that 8x8 quadrant accepts the splat in the oracle (fp32 and fp64); and for small splats it does
+    clear a useful share of the quadrants of the (splat, tile) instances that survive the tile-level test."""
+    scene, cam = S.make_scene(8000, 256, 192, 0, 93, scale_lo=0.002, scale_hi=0.05), S.make_camera(256, 192)
+    kw = raster_kwargs(scene, cam)
+    fr = oracle.rasterize(dtype=np.float32, **kw)
+    fr64 = oracle.rasterize(dtype=np.float64, **kw)
+    got = _run(hh, kw)
+    vis = np.nonzero(fr.radii > 0)[0]
+    gs, txs, tys = [], [], []
+    for g in vis:
+        x0, y0, x1, y1 = fr.rect[g]
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        gs.append(np.full(xx.size, g)); txs.append(xx.ravel()); tys.append(yy.ravel())
+    g = np.concatenate(gs); tx = np.concatenate(txs).astype(np.int32); ty = np.concatenate(tys).astype(np.int32)
+    rec = np.ascontiguousarray(got["rec"][g], np.float32)
+    mask = np.zeros(g.size, np.uint8)
+    hh.hh_quadrant_mask(g.size, _p(rec), _p(tx), _p(ty), _p(mask))
+    # brute force: per instance and quadrant, does any pixel accept?
+    px = (tx[:, None] * 16 + np.arange(16)[None, :])[:, None, :]
+    py = (ty[:, None] * 16 + np.arange(16)[None, :])[:, :, None]
+    for frx in (fr, fr64):
+        co_ = frx.conic_opacity[g].astype(np.float64)
+        dx = frx.xy[g, 0].astype(np.float64)[:, None, None] - px
+        dy = frx.xy[g, 1].astype(np.float64)[:, None, None] - py
+        power = -0.5 * (co_[:, 0, None, None] * dx * dx + co_[:, 2, None, None] * dy * dy) - co_[:, 1, None, None] * dx * dy
+        alpha = np.minimum(0.99, co_[:, 3, None, None] * np.exp(np.minimum(power, 0)))
+        accept = (power <= 0) & (alpha >= (1 / 255) * (1 - 1e-3))                         # [n, 16 (y), 16 (x)]
+        for k in range(4):
+            qa = accept[:, (k >> 1) * 8:(k >> 1) * 8 + 8, (k & 1) * 8:(k & 1) * 8 + 8].any((1, 2))
+            clear = (mask >> k) & 1 == 0
+            assert not (qa & clear).any(), f"quadrant {k}: {(qa & clear).sum()} culled quadrants hold an accepting pixel"
+    n_set = sum(((mask >> k) & 1).sum() for k in range(4))
+    reach = mask != 0
+    assert 0.3 < n_set / (4.0 * reach.sum()) < 0.85, n_set / (4.0 * reach.sum())
+
+
 def test_raw_activations_match_torch_autograd(hh):
     """csrc/gsr_math.h activate_raw / activate_raw_backward (raw-parameter mode) against torch
     autograd through the reference's activations (scene/gaussian_model.py:47-60: exp, sigmoid,
