@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 7
+#define GSR_VERSION 8
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -74,6 +74,8 @@ typedef struct gsr_frame_plan {
     int32_t binning_initialised;                  /* gsr_forward_preprocess was given the image workspace and has
                                                      already reset the tile ranges / open flags in it        */
     int32_t screen_prezeroed;                     /* set by gsr_backward_prepare: screen_grads is already all zero   */
+    int64_t binning_capacity;                     /* IN to gsr_forward_render (and the backward): instances the binning
+                                                     workspace was sized for (gsr_binning_size of that number); 0 = R   */
 } gsr_frame_plan;
 
 typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */
@@ -115,8 +117,13 @@ const char *gsr_last_error(void);
  * `_C.rasterize_gaussians` allocates through its resize callback). */
 int gsr_workspace_sizes(const gsr_frame_desc *desc, size_t *geom_bytes, size_t *image_bytes);
 
-/* Size of the per-duplicate workspace (the reference's binningBuffer) for R = num_rendered. */
+/* Size of the per-duplicate workspace (the reference's binningBuffer) for `num_rendered` instances: 24 bytes each.
+ * The reference sizes it for R = plan->num_rendered.  Here only what the depth chunks actually emit is touched (2-8 % of R
+ * on frames whose tiles saturate), so a caller may size it for gsr_binning_first_chunk_capacity() instances, set
+ * plan->binning_capacity to that number, and fall back to R when gsr_forward_render answers GSR_ERR_WORKSPACE (a later
+ * chunk did not fit; nothing of it was written: re-run gsr_forward_render with the larger workspace). */
 int gsr_binning_size(const gsr_frame_desc *desc, int64_t num_rendered, size_t *binning_bytes);
+int gsr_binning_first_chunk_capacity(const gsr_frame_plan *plan_host, int64_t *instances);
 
 /* Stage 1 of `_C.rasterize_gaussians`: per-Gaussian preprocess (cull, project, EWA covariance,
  * SH colour), depth sort of the Gaussians, prefix sum of tiles touched in depth order, chunk plan.
@@ -200,6 +207,12 @@ int gsr_loss_l1_ssim_forward(int32_t channels, int32_t height, int32_t width, fl
 int gsr_loss_l1_ssim_backward(int32_t channels, int32_t height, int32_t width, float lambda_dssim, const float *upstream,
                               const float *image, const float *target, const void *workspace, float *grad_image,
                               void *stream);
+/* The two terms on their own, for a caller that composes the loss itself exactly as train.py:104-105 does
+ * (Ll1 = l1_loss(image, gt); loss = (1 - lambda) * Ll1 + lambda * (1 - ssim(image, gt))): gsr_loss_l1_ssim_forward's
+ * out3[1] / out3[2] ARE l1_loss / ssim of utils/loss_utils.py:17-18,33-63; d ssim / d image is gsr_loss_l1_ssim_backward
+ * with lambda_dssim = 1 and the upstream negated; d l1_loss / d image = upstream[0] * sign(image - target) / n is this: */
+int gsr_loss_l1_backward(int64_t n, const float *upstream, const float *image, const float *target, float *grad_image,
+                         void *stream);
 /* Multi-GPU slab variants (SURVEY 8e "slab-local loss"): this rank owns image rows [row_begin, row_end) of a
  * full-size image whose rows within 10 of the slab are valid.  forward_rows writes out2 = (sum |image - target|,
  * sum of the SSIM map) over the slab's rows — un-normalised: the caller adds the ranks' pairs and forms

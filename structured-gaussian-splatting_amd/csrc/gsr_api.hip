@@ -3,7 +3,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "gsr_internal.h"
@@ -132,6 +134,17 @@ static int validate_inputs(const gsr_frame_desc *d, const gsr_camera *c, const g
 // Control-block readback: the two host decisions of a frame (R / chunk plan, open-tile count) wait for 160 bytes.
 // The copy lands in pinned memory and the host POLLS an event instead of sleeping in hipStreamSynchronize: the
 // blocking wait's wake-up costs tens of microseconds of idle stream per readback at a 1.5 ms step.
+constexpr double kReadbackTimeoutS = 30.0;
+
+static inline void cpu_pause()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+}
+
 struct Readback {            // one per host thread, never freed (160 pinned bytes + an event; the HIP runtime may already be
     Ctrl *pinned = nullptr;  // gone when thread-local destructors run)
     hipEvent_t ev = nullptr;
@@ -147,10 +160,26 @@ static int read_ctrl(const Ctrl *dev, Ctrl *out, hipStream_t s)
     }
     GSR_HIP_CHECK(hipMemcpyAsync(rb.pinned, dev, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
     GSR_HIP_CHECK(hipEventRecord(rb.ev, s));
-    for (;;) {
+    // Poll, politely and not for ever: a few thousand queries back to back (the readback normally lands within tens of
+    // microseconds), then with a pause instruction between queries, and after kReadbackTimeoutS give up with an error
+    // instead of hanging the host on a wedged stream.
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long long spins = 0;; ++spins) {
         const hipError_t e = hipEventQuery(rb.ev);
         if (e == hipSuccess) break;
         if (e != hipErrorNotReady) { set_error("control-block readback: %s", hipGetErrorString(e)); return GSR_ERR_HIP; }
+        if (spins > 4096) {
+            cpu_pause();
+            if ((spins & 1023) == 0) {
+                if (spins > (1ull << 16)) std::this_thread::yield();         // a long wait (debugger, huge frame): give the core away
+                const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > kReadbackTimeoutS) {
+                    set_error("control-block readback did not complete within %.0f s: the stream is stuck (a kernel of this frame "
+                              "hangs or the device was lost)", kReadbackTimeoutS);
+                    return GSR_ERR_HIP;
+                }
+            }
+        }
     }
     *out = *rb.pinned;
     return GSR_OK;
@@ -182,6 +211,16 @@ int gsr_binning_size(const gsr_frame_desc *desc, int64_t num_rendered, size_t *b
     if (rc) return rc;
     if (num_rendered < 0 || !binning_bytes) { set_error("bad num_rendered / NULL out"); return GSR_ERR_INVALID_ARGUMENT; }
     *binning_bytes = carve_binning(nullptr, num_rendered).total;
+    return GSR_OK;
+}
+
+int gsr_binning_first_chunk_capacity(const gsr_frame_plan *plan, int64_t *instances)
+{
+    if (!plan || !instances) { set_error("gsr_binning_first_chunk_capacity: NULL argument"); return GSR_ERR_INVALID_ARGUMENT; }
+    // what the first depth chunk can emit at most, plus headroom for a small straggler chunk; never more than R
+    int64_t n = plan->num_chunks > 1 ? plan->chunk_instances_max[0] + plan->chunk_instances_max[0] / 4 + (1 << 20) : plan->num_rendered;
+    if (n > plan->num_rendered) n = plan->num_rendered;
+    *instances = n;
     return GSR_OK;
 }
 
@@ -258,19 +297,30 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         return GSR_OK;
     }
     GeomWS gw = carve_geom(geom_ws, f.P);
-    BinningWS bw = carve_binning(binning_ws, plan->num_rendered);
+    // The binning workspace holds `binning_capacity` instances (0: the upper bound R, as the reference sizes its
+    // binningBuffer).  A frame whose tiles saturate runs one small depth chunk and touches a few per cent of R, so
+    // callers may size it for the first chunk only; a later chunk that does not fit stops the frame with
+    // GSR_ERR_WORKSPACE before anything of that chunk is written (re-run this stage with a workspace for R instances).
+    const int64_t capacity = plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered;
+    BinningWS bw = carve_binning(binning_ws, capacity);
     if (!plan->binning_initialised && (rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
+    plan->binning_initialised = 0;                  // a re-run of this stage must reset the tile ranges / open flags itself
     int sort_result = 0;
-    uint64_t cand_before = 0;                       // upper bound of the instances earlier chunks can have emitted
+    uint64_t emitted_before = 0;                    // instances earlier chunks emitted (exact: read back with the open-tile count)
     // Early stop: one control-block readback per chunk (~10 us of stream idle, measured); the chunk plan keeps
     // the number of chunks at three or fewer.
     for (int c = 0; c < plan->num_chunks; ++c) {
         const bool last = c == plan->num_chunks - 1;
         const int r0 = plan->chunk_rank_begin[c], r1 = plan->chunk_rank_begin[c + 1];
-        if ((rc = launch_chunk_binning(f, c, r0, r1, (uint64_t)plan->chunk_instances_max[c], cand_before, gw, bw, iw, &sort_result,
+        if (emitted_before + (uint64_t)plan->chunk_instances_max[c] > (uint64_t)capacity) {
+            set_error("binning workspace holds %lld instances, depth chunk %d may need %llu: re-run gsr_forward_render with "
+                      "binning_capacity = num_rendered (%lld)", (long long)capacity, c,
+                      (unsigned long long)(emitted_before + (uint64_t)plan->chunk_instances_max[c]), (long long)plan->num_rendered);
+            return GSR_ERR_WORKSPACE;
+        }
+        if ((rc = launch_chunk_binning(f, c, r0, r1, (uint64_t)plan->chunk_instances_max[c], emitted_before, gw, bw, iw, &sort_result,
                                        dbg, s)))
             return rc;
-        cand_before += (uint64_t)plan->chunk_instances_max[c];
         if ((rc = launch_chunk_colors(f, *cam, *g, r0, r1, gw, dbg, s))) return rc;      // A.6 for this chunk's Gaussians only
         if ((rc = launch_render_fwd(f, *cam, c, last, gw, bw, iw, out_color, dbg, s))) return rc;
         plan->chunks_run = c + 1;
@@ -280,6 +330,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         Ctrl h;
         if ((rc = read_ctrl(gw.ctrl, &h, s))) return rc;
         plan->instances_emitted = (int64_t)h.chunk_base[c + 1];
+        emitted_before = (uint64_t)h.chunk_base[c + 1];
         if (h.open_count == 0) break;
     }
     plan->sort_result = sort_result;
@@ -335,7 +386,7 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     if (f.P == 0) return GSR_OK;
     GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
     ImageWS iw = carve_image(const_cast<void *>(image_ws), f);
-    BinningWS bw = carve_binning(binning_ws, plan->num_rendered);
+    BinningWS bw = carve_binning(binning_ws, plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered);
     bw.grad_rows = (float *)rows_ws;
     if (plan->num_rendered > 0 &&
         (rc = launch_render_bwd(f, *cam, plan->chunks_run, plan->sort_result, gw, bw, iw, dL_dcolor, dbg, s)))
@@ -439,7 +490,7 @@ int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const v
         v->clamped = gw.clamped;
     }
     if (binning_ws) {
-        BinningWS bw = carve_binning(const_cast<void *>(binning_ws), plan->num_rendered);
+        BinningWS bw = carve_binning(const_cast<void *>(binning_ws), plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered);
         v->sorted_gaussian = bw.sorted_gid;
     }
     if (image_ws) {

@@ -589,7 +589,7 @@ static int msb_plus1(uint32_t n)
     return b;
 }
 
-int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, uint64_t cand_before, GeomWS &gw, BinningWS &bw,
+int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, uint64_t emitted_before, GeomWS &gw, BinningWS &bw,
                          ImageWS &iw,
                          int *sort_result, bool debug, hipStream_t s)
 {
@@ -603,8 +603,10 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     const bool flat = avg < 24;
     const int team = avg >= 1024 ? 16 : avg >= 96 ? 4 : 1;
     const int bin_blocks = (n + kBinBlock - 1) / kBinBlock;      // B: 64 depth ranks per wave, 4 waves per block
-    // A's mask scratch: the idle half of the radix double buffer beyond everything earlier chunks can have written
-    unsigned long long *masks = reinterpret_cast<unsigned long long *>(bw.keys[1] + ((cand_before + 1) & ~(uint64_t)1));
+    // A's mask scratch: the idle half of the radix double buffer beyond everything earlier chunks have written (their exact
+    // emitted count; ceil(n_max / 64) + n words of 8 bytes fit in the n_max slots the caller has checked are there: a team
+    // chunk averages >= 24 tiles per Gaussian)
+    unsigned long long *masks = reinterpret_cast<unsigned long long *>(bw.keys[1] + ((emitted_before + 1) & ~(uint64_t)1));
     {
         ProfileScope prof("count_open", s);
 #define GSR_CT(W)                                                                                                          \

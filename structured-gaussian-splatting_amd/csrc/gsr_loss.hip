@@ -341,7 +341,31 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int C, int H, int W, LossR
 
 using namespace gsr;
 
+// d mean|a - b| / da = sign(a - b) / n (sign(0) = 0, as torch.abs): the backward of the reference's l1_loss on its own
+__global__ __launch_bounds__(kLBlock) void k_l1_bwd(long long n, float inv_n, const float *__restrict__ upstream, const float *__restrict__ a,
+                                                    const float *__restrict__ b, float *__restrict__ g)
+{
+    const float s = (upstream ? upstream[0] : 1.f) * inv_n;
+    for (long long i = (long long)blockIdx.x * kLBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kLBlock) {
+        const float d = a[i] - b[i];
+        g[i] = d > 0.f ? s : (d < 0.f ? -s : 0.f);
+    }
+}
+
 extern "C" {
+
+int gsr_loss_l1_backward(int64_t n, const float *upstream, const float *image, const float *target, float *grad_image, void *stream)
+{
+    if (n < 0 || (n > 0 && (!image || !target || !grad_image))) { set_error("gsr_loss_l1_backward: bad argument"); return GSR_ERR_INVALID_ARGUMENT; }
+    if (n == 0) return GSR_OK;
+    long long blocks = (n + kLBlock * 4 - 1) / (kLBlock * 4);
+    if (blocks > 4096) blocks = 4096;
+    ProfileScope prof("loss_bwd", (hipStream_t)stream);
+    hipLaunchKernelGGL(k_l1_bwd, dim3((unsigned)blocks), dim3(kLBlock), 0, (hipStream_t)stream, (long long)n, 1.f / (float)n, upstream, image,
+                       target, grad_image);
+    GSR_LAUNCH_CHECK("l1_bwd", false, (hipStream_t)stream);
+    return GSR_OK;
+}
 
 int gsr_loss_workspace_size(int32_t channels, int32_t height, int32_t width, size_t *bytes)
 {

@@ -63,7 +63,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(-(-n // step) * step, dtype=torch.uint8, device=device)
 
 
-_binning_guess = {}        # (P, W, H, slab, device) -> bytes of the last binning workspace of that frame shape
+_binning_guess = {}        # (P, W, H, slab, device) -> instances the binning workspace of that frame shape last had to hold
 
 
 class _Frame:
@@ -129,16 +129,28 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
             color = (torch.empty if tile_rows is None else torch.zeros)(3, H, W, dtype=torch.float32, device=device)
         guess_key = (P, W, H, None if tile_rows is None else tuple(int(v) for v in tile_rows), device.index)
         guess = _binning_guess.get(guess_key, 0)
-        binning = _workspace(guess, device) if guess > 0 else None
+        binning = _workspace(N.binning_size(fr.desc, guess), device) if guess > 0 else None
         fr.plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device, image_ws=fr.image_ws)
-        need = N.binning_size(fr.desc, fr.R)
-        if binning is None or binning.numel() < need:
-            binning = _workspace(need, device)
-        _binning_guess[guess_key] = need
+        # The binning workspace (24 B per instance) is sized for what the FIRST depth chunk can emit, not for the upper bound R
+        # of every chunk (11.8 GB at 5e6 Gaussians / 4K): frames whose tiles saturate never get past that chunk.  A frame that
+        # does need more stops with GSR_ERR_WORKSPACE before it writes anything it has no room for, and is re-run once with a
+        # workspace for R; frames of that shape then start with R.
+        capacity = max(min(N.binning_first_chunk_capacity(fr.plan), fr.R), min(guess, fr.R))
+        while True:
+            if binning is None or binning.numel() < N.binning_size(fr.desc, capacity):
+                binning = _workspace(N.binning_size(fr.desc, capacity), device)
+            fr.plan.binning_capacity = capacity
+            fr.binning_ws = binning
+            try:
+                N.forward_render(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, color, device)
+                break
+            except N.GsrError as e:
+                if e.status != N.ERR_WORKSPACE or capacity >= fr.R:
+                    raise
+                capacity, binning = fr.R, None
+        _binning_guess[guess_key] = capacity
         if len(_binning_guess) > 64:
             _binning_guess.pop(next(iter(_binning_guess)))
-        fr.binning_ws = binning
-        N.forward_render(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, color, device)
     return color, fr.radii, fr
 
 
@@ -183,7 +195,8 @@ def prepare_backward(fr: "_Frame", needs) -> None:
     through the caller's code to the loss, so the backward's zero fills (screen-space gradients + the parameter
     gradients of the sparse geometry backward, ~280 MB at 1e6 Gaussians) are enqueued NOW, in one launch."""
     P, plan = fr.desc.P, fr.plan
-    if P == 0 or plan.num_rendered <= 0 or plan.chunks_run <= 0 or not any(needs):
+    # ctx.needs_input_grad stays True for leaf parameters under torch.no_grad() (eval / test-view renders): no backward can follow
+    if P == 0 or plan.num_rendered <= 0 or plan.chunks_run <= 0 or not any(needs) or not torch.is_grad_enabled():
         return
     if int(plan.chunk_rank_begin[plan.chunks_run]) * 4 >= P:
         return                                  # the dense geometry backward writes every row itself
@@ -227,6 +240,39 @@ def _dump(path, payload):
         pass
 
 
+_FRAME_TENSORS = ("geom_ws", "binning_ws", "image_ws", "radii")
+
+
+def _stash_frame(ctx, frame):
+    """Hand the frame's device buffers (workspaces, radii, the contiguous input copies) to autograd's saved-tensor slots:
+    like the upstream extension's saved buffers they are released right after backward() — or kept, and a second
+    backward() allowed, under retain_graph=True; a second backward() without it raises autograd's usual error."""
+    keep = [t for t in frame.keep[1:] if t is not None]
+    ctx.save_for_backward(*(getattr(frame, n) for n in _FRAME_TENSORS), *frame.keep[0], *keep)
+    ctx.frame_keep_mask = tuple(t is not None for t in frame.keep[1:])
+    for n in _FRAME_TENSORS:
+        setattr(frame, n, None)
+    frame.keep = None
+    ctx.frame = frame
+
+
+def _unstash_frame(ctx):
+    fr = ctx.frame
+    saved = ctx.saved_tensors                      # raises if the graph's buffers were already freed
+    for n, t in zip(_FRAME_TENSORS, saved[:4]):
+        setattr(fr, n, t)
+    it = iter(saved[8:])
+    fr.keep = (tuple(saved[4:8]),) + tuple(next(it) if m else None for m in ctx.frame_keep_mask)
+    return fr
+
+
+def _restash_frame(fr):
+    for n in _FRAME_TENSORS:
+        setattr(fr, n, None)
+    fr.keep = None
+    fr.plan.screen_prezeroed = 0
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -245,7 +291,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             color, radii, frame = rasterize_forward(*args, rs)
             prepare_backward(frame, tuple(ctx.needs_input_grad[:8]))
-        ctx.frame = frame
+        _stash_frame(ctx, frame)
         ctx.raster_settings = rs
         ctx.shapes = (means2D.shape, opacities.shape)
         ctx.mark_non_differentiable(radii)
@@ -253,7 +299,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
-        fr, rs = ctx.frame, ctx.raster_settings
+        fr, rs = _unstash_frame(ctx), ctx.raster_settings
         needs = tuple(ctx.needs_input_grad[:8])
         # input order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp
         order = (needs[0], needs[1], needs[2], needs[3], needs[4], needs[5], needs[6], needs[7])
@@ -277,7 +323,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             g_op = g_op.view(ctx.shapes[1])
         if g_means2D is not None:
             g_means2D = g_means2D.view(ctx.shapes[0])
-        ctx.frame = None
+        _restash_frame(fr)
         return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None
 
 
@@ -295,14 +341,14 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             torch.cuda.synchronize(xyz.device)
         n = ctx.needs_input_grad       # xyz, means2D, f_dc, f_rest, opacity, scales, rotations
         prepare_backward(frame, (n[0], n[1], n[2], False, n[4], n[5], n[6], False, n[3]))
-        ctx.frame = frame
+        _stash_frame(ctx, frame)
         ctx.shapes = (means2D.shape, opacity_logits.shape)
         ctx.mark_non_differentiable(radii)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _grad_radii):
-        fr = ctx.frame
+        fr = _unstash_frame(ctx)
         n = ctx.needs_input_grad       # xyz, means2D, f_dc, f_rest, opacity, scales, rotations
         needs = (n[0], n[1], n[2], False, n[4], n[5], n[6], False, n[3])
         screen = rasterize_backward_screen(fr, grad_out_color)
@@ -311,7 +357,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             g_op = g_op.view(ctx.shapes[1])
         if g_means2D is not None:
             g_means2D = g_means2D.view(ctx.shapes[0])
-        ctx.frame = None
+        _restash_frame(fr)
         return g_xyz, g_means2D, g_dc, g_rest, g_op, g_sc, g_rot, None
 
 

@@ -51,7 +51,7 @@ class FramePlan(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("num_chunks", C.c_int32),
                 ("chunk_rank_begin", C.c_int32 * (MAX_CHUNKS + 1)), ("chunk_instances_max", C.c_int64 * MAX_CHUNKS),
                 ("chunks_run", C.c_int32), ("sort_result", C.c_int32), ("instances_emitted", C.c_int64),
-                ("binning_initialised", C.c_int32), ("screen_prezeroed", C.c_int32)]
+                ("binning_initialised", C.c_int32), ("screen_prezeroed", C.c_int32), ("binning_capacity", C.c_int64)]
 
 
 class DebugViews(C.Structure):
@@ -60,9 +60,9 @@ class DebugViews(C.Structure):
                 ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p)]
 
 
-EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_forward_preprocess",
+EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess",
            "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
-           "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows",
+           "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows", "gsr_loss_l1_backward",
            "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_densify_stats")
 
 _lib = None
@@ -97,13 +97,18 @@ def load():
 
 
 class GsrError(RuntimeError):
-    pass
+    status = 0
+
+
+ERR_WORKSPACE = -4
 
 
 def _check(rc: int, what: str):
     if rc != 0:
         msg = load().gsr_last_error().decode("utf-8", "replace")
-        raise GsrError(f"{what} failed (status {rc}): {msg}")
+        e = GsrError(f"{what} failed (status {rc}): {msg}")
+        e.status = rc
+        raise e
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -133,6 +138,12 @@ def binning_size(desc: FrameDesc, R: int) -> int:
     b = C.c_size_t(0)
     _check(load().gsr_binning_size(C.byref(desc), C.c_int64(R), C.byref(b)), "gsr_binning_size")
     return b.value
+
+
+def binning_first_chunk_capacity(plan: FramePlan) -> int:
+    n = C.c_int64(0)
+    _check(load().gsr_binning_first_chunk_capacity(C.byref(plan), C.byref(n)), "gsr_binning_first_chunk_capacity")
+    return n.value
 
 
 def forward_preprocess(desc, cam: Camera, g: Gaussians, geom_ws, radii, device, image_ws=None) -> FramePlan:
@@ -182,7 +193,7 @@ def debug_views(desc, geom_ws, binning_ws, image_ws, plan: FramePlan) -> dict:
     v = DebugViews()
     _check(load().gsr_debug_get_views(C.byref(desc), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws), C.byref(plan),
                                       C.byref(v)), "gsr_debug_get_views")
-    P, N, R = desc.P, desc.width * desc.height, int(plan.num_rendered)
+    P, N, R = desc.P, desc.width * desc.height, int(plan.binning_capacity or plan.num_rendered)
     Tn = ((desc.width + 15) // 16) * ((desc.height + 15) // 16)
 
     def view(ws, addr, nbytes, dtype, shape):
@@ -237,6 +248,11 @@ def loss_backward(image, target, lam, upstream, workspace, grad_image):
     _check(load().gsr_loss_l1_ssim_backward(C.c_int32(Cn), C.c_int32(H), C.c_int32(W), C.c_float(lam), _ptr(upstream),
                                             _ptr(image), _ptr(target), _ptr(workspace), _ptr(grad_image),
                                             _stream(image.device)), "gsr_loss_l1_ssim_backward")
+
+
+def loss_l1_backward(image, target, upstream, grad_image):
+    _check(load().gsr_loss_l1_backward(C.c_int64(image.numel()), _ptr(upstream), _ptr(image), _ptr(target), _ptr(grad_image),
+                                       _stream(image.device)), "gsr_loss_l1_backward")
 
 
 def loss_forward_rows(image, target, workspace, out2, row_begin, row_end):

@@ -203,7 +203,7 @@ class _ShardedRasterize(torch.autograd.Function):
             mine[0, :n_words].view(3, rows_max, W)[:, :y1 - y0] = full[:, y0:y1]
         needs = tuple(ctx.needs_input_grad[:8]) + ((bool(ctx.needs_input_grad[10]),) if raw else ())
         ctx.needs = needs
-        want_prefix = shard.backward_mode == "allreduce_screen" and any(needs)
+        want_prefix = shard.backward_mode == "allreduce_screen" and any(needs) and torch.is_grad_enabled()
         order, n_mine = backend.binned_prefix(frame) if want_prefix else (None, 0)
         mine[0, n_words].fill_(float(int(n_mine) >> 16))
         mine[0, n_words + 1].fill_(float(int(n_mine) & 0xFFFF))
@@ -377,9 +377,10 @@ class ShardedRenderer:
             scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
             projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
             campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+        frozen = any(getattr(pc, f, False) for f in ("freeze_means", "freeze_scales", "freeze_rotations", "freeze_opacities"))
         if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.compute_cov3D_python
                 and not getattr(pipe, "convert_SHs_python", False) and hasattr(pc, "_features_rest") and pc._features_rest.numel()
-                and isinstance(self.backend, NativeBackend)):
+                and isinstance(self.backend, NativeBackend) and not frozen):      # frozen parameters: the getters' detach() must run
             rs = rs._replace(sh_degree=int(rs.sh_degree))
             e = torch.empty(0, dtype=torch.float32, device=xyz.device)
             image, radii = _ShardedRasterize.apply(pc._xyz, screenspace_points, pc._features_dc, e, pc._opacity, pc._scaling,

@@ -59,8 +59,12 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
+    # the fused path hands the RAW parameters to the kernels and so bypasses the getters — and with them the reference's
+    # freeze flags (scene/gaussian_model.py:104-125 detach() the getter's result): a model with any of them set takes the
+    # plain path, where a frozen parameter receives no gradient
+    frozen = any(getattr(pc, f, False) for f in ("freeze_means", "freeze_scales", "freeze_rotations", "freeze_opacities"))
     if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.compute_cov3D_python
-            and not pipe.convert_SHs_python and hasattr(pc, "_features_rest")):
+            and not pipe.convert_SHs_python and hasattr(pc, "_features_rest") and not frozen):
         rendered_image, radii = rasterizer.forward_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest,
                                                        pc._opacity, pc._scaling, pc._rotation)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,

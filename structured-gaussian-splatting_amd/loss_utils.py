@@ -1,14 +1,31 @@
 """The loss of the reference's timed training window (train.py:104-105): L1 and D-SSIM, plus PSNR.
-Host-side mirror of utils/loss_utils.py:17-63 and utils/image_utils.py:14-19 in plain torch (these run
-unmodified on ROCm); pinned by tests/golden/loss.npz."""
+
+Drop-in for the reference's utils/loss_utils.py (same names, signatures and values: `l1_loss(network_output, gt)`,
+`l2_loss`, `ssim(img1, img2, window_size=11, size_average=True)`) and utils/image_utils.py:14-19 (`psnr`), pinned by
+tests/golden/loss.npz.  On a HIP device `l1_loss` and `ssim` are autograd ops over the fused kernels of
+csrc/gsr_loss.hip, so train.py:104-105 as written —
+
+    Ll1 = l1_loss(image, gt_image)
+    loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, gt_image))
+
+— needs nothing but this module on the import path: the two calls share ONE fused forward (the second finds the first's
+result for the same two tensors), and each has its own backward kernel.  `training_loss()` is the same composition as one
+op (one forward, one backward launch).  `*_torch` are the plain-torch forms (CPU tensors, other window sizes, batches)."""
 import math
 
 import torch
 import torch.nn.functional as F
 
 
-def l1_loss(network_output, gt):
+def l1_loss_torch(network_output, gt):
     return torch.abs(network_output - gt).mean()
+
+
+def l1_loss(network_output, gt):
+    """utils/loss_utils.py:17-18."""
+    if _fusable(network_output, gt):
+        return _L1.apply(network_output, gt)
+    return l1_loss_torch(network_output, gt)
 
 
 def l2_loss(network_output, gt):
@@ -26,6 +43,13 @@ _WINDOWS = {}
 
 
 def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
+    """utils/loss_utils.py:33-63 (11x11 Gaussian window sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2)."""
+    if window_size == 11 and size_average and _fusable(img1, img2):
+        return _SSIM.apply(img1, img2)
+    return ssim_torch(img1, img2, window_size, size_average)
+
+
+def ssim_torch(img1, img2, window_size: int = 11, size_average: bool = True):
     channel = img1.size(-3)
     key = (window_size, channel, img1.device, img1.dtype)
     if key not in _WINDOWS:
@@ -45,7 +69,70 @@ def ssim(img1, img2, window_size: int = 11, size_average: bool = True):
 def training_loss_torch(image, gt, lambda_dssim: float = 0.2):
     """(1 - lambda) L1 + lambda (1 - SSIM), train.py:104-105 with arguments/__init__.py:89's default,
     in plain torch ops exactly as the reference composes it."""
-    return (1.0 - lambda_dssim) * l1_loss(image, gt) + lambda_dssim * (1.0 - ssim(image, gt))
+    return (1.0 - lambda_dssim) * l1_loss_torch(image, gt) + lambda_dssim * (1.0 - ssim_torch(image, gt))
+
+
+def _fusable(a, b) -> bool:
+    return (a.is_cuda and b.is_cuda and a.dim() == 3 and a.shape == b.shape and a.dtype == torch.float32 and b.dtype == torch.float32
+            and not b.requires_grad)
+
+
+_shared = None          # the last fused forward: (image, its version, target, its version, contiguous inputs, workspace, out3)
+
+
+def _shared_forward(image, gt):
+    """One fused forward for l1_loss(image, gt) and ssim(image, gt) called one after the other on the SAME tensors (identity
+    and version checked; the cached entry keeps them alive, so an address cannot be reused under it)."""
+    global _shared
+    from diff_gaussian_rasterization import _native as N
+    c = _shared
+    if c is not None and c[0] is image and c[1] == image._version and c[2] is gt and c[3] == gt._version:
+        _shared = None                                            # second consumer: nothing else will ask for this pair
+        return c[4], c[5], c[6], c[7]
+    img, tgt = image.detach().contiguous(), gt.detach().contiguous()
+    ws = torch.empty(N.loss_workspace_size(*img.shape), dtype=torch.uint8, device=img.device)
+    out3 = torch.empty(3, dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        N.loss_forward(img, tgt, 0.0, ws, out3)
+    _shared = (image, image._version, gt, gt._version, img, tgt, ws, out3)
+    return img, tgt, ws, out3
+
+
+class _L1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt):
+        img, tgt, _, out3 = _shared_forward(image, gt)
+        ctx.save_for_backward(img, tgt)
+        return out3[1].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from diff_gaussian_rasterization import _native as N
+        img, tgt = ctx.saved_tensors
+        grad = torch.empty_like(img)
+        up = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        with torch.cuda.device(img.device):
+            N.loss_l1_backward(img, tgt, up, grad)
+        return grad, None
+
+
+class _SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt):
+        img, tgt, ws, out3 = _shared_forward(image, gt)
+        ctx.save_for_backward(img, tgt, ws)
+        return out3[2].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from diff_gaussian_rasterization import _native as N
+        img, tgt, ws = ctx.saved_tensors
+        grad = torch.empty_like(img)
+        # the kernel differentiates (1 - lambda) L1 + lambda (1 - SSIM): lambda = 1 and a negated upstream give d SSIM / d image
+        up = (-grad_out.detach().to(torch.float32)).reshape(1).contiguous()
+        with torch.cuda.device(img.device):
+            N.loss_backward(img, tgt, 1.0, up, ws, grad)
+        return grad, None
 
 
 class _FusedL1SSIM(torch.autograd.Function):

@@ -7,6 +7,11 @@ What it pins: the in-tree twins of the rasterizer's sub-ste
   utils/graphics_utils.py:22-77   view/projection matrices, point xf -> camera.npz
   utils/loss_utils.py:17-63, utils/image_utils.py:14-19  losses      -> loss.npz
   utils/general_utils.py:29-62    get_expon_lr_func                   -> lr.npz
+  utils/general_utils.py:64-110   build_rotation, build_scaling_rotation, strip_symmetric (A.3: quaternion -> R,
+                                  L = R S, Sigma = L L^T packed [xx,xy,xz,yy,yz,zz]) and the covariance builder of
+                                  scene/gaussian_model.py:25-29                                              -> cov3d.npz
+                                  (those functions hard-code device="cuda"; HERE ONLY the torch factory they call is
+                                  wrapped to drop that keyword so that they run on the CPU of the authoring container)
   arguments/__init__.py:47-95     default hyper-parameters            -> params.json
 Only inputs and expected outputs are stored (data, not source).
 
@@ -111,7 +116,44 @@ def loss_vectors():
         out[f"a{i}"] = a.detach().numpy(); out[f"b{i}"] = b.numpy()
         out[f"l1_{i}"] = l1.item(); out[f"ssim_{i}"] = s.item(); out[f"loss_{i}"] = loss.item()
         out[f"grad_a{i}"] = a.grad.numpy(); out[f"psnr_{i}"] = psnr(a.detach(), b).numpy()
+        # each function's own gradient (the drop-in l1_loss / ssim autograd ops are checked one by one)
+        a2 = a.detach().clone().requires_grad_(True)
+        l1_loss(a2, b).backward()
+        out[f"grad_l1_a{i}"] = a2.grad.numpy()
+        a3 = a.detach().clone().requires_grad_(True)
+        ssim(a3, b).backward()
+        out[f"grad_ssim_a{i}"] = a3.grad.numpy()
     np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+
+def cov3d_vectors():
+    """A.3 from the reference's own functions.  utils/general_utils.py:65,83,102 create their outputs with
+    device="cuda"; in this container (no GPU) that keyword is dropped by wrapping torch.zeros for the duration of the
+    calls - nothing else about the functions is touched."""
+    import utils.general_utils as gu
+    real_zeros = torch.zeros
+
+    def zeros_anywhere(*a, **k):
+        if str(k.get("device", "")).startswith("cuda"):
+            k.pop("device")
+        return real_zeros(*a, **k)
+    g = torch.Generator().manual_seed(2024)
+    P = 64
+    q = torch.randn(P, 4, generator=g, dtype=torch.float32)            # un-normalised: build_rotation normalises itself
+    s = torch.exp(torch.rand(P, 3, generator=g) * 4.0 - 5.0)           # scales over two decades
+    mods = (1.0, 1.7)
+    out = dict(rotation=q.numpy(), scaling=s.numpy(), modifiers=np.array(mods))
+    torch.zeros = zeros_anywhere
+    try:
+        out["R"] = gu.build_rotation(q).numpy()
+        for j, m in enumerate(mods):
+            L = gu.build_scaling_rotation(m * s, q)                   # scene/gaussian_model.py:25-29
+            cov = L @ L.transpose(1, 2)
+            out[f"L_{j}"] = L.numpy()
+            out[f"cov6_{j}"] = gu.strip_symmetric(cov).numpy()
+    finally:
+        torch.zeros = real_zeros
+    np.savez_compressed(os.path.join(OUT, "cov3d.npz"), **out)
 
 
 def lr_vectors():
@@ -130,5 +172,9 @@ def param_defaults():
 
 
 if __name__ == "__main__":
-    sh_vectors(); camera_vectors(); loss_vectors(); lr_vectors(); param_defaults()
+    only = set(sys.argv[1:])
+    for name, fn in (("sh", sh_vectors), ("camera", camera_vectors), ("loss", loss_vectors), ("lr", lr_vectors),
+                     ("params", param_defaults), ("cov3d", cov3d_vectors)):
+        if not only or name in only:
+            fn()
     print("golden vectors written to", OUT)

@@ -66,6 +66,12 @@ extern "C" void hh_tile_may_contribute(int n, const float *sx, const float *sy, 
     for (int i = 0; i < n; ++i) out[i] = tile_may_contribute(sx[i], sy[i], A[i], B[i], C[i], op[i], tx[i], ty[i]) ? 1 : 0;
 }
 
+// A.3: packed covariance from scale * modifier and a (normalised) quaternion
+extern "C" void hh_cov3d(int n, const float *scales, const float *quats, float mod, float *cov6)
+{
+    for (int i = 0; i < n; ++i) cov3d_from_scale_rot(scales + 3 * i, mod, quats + 4 * i, cov6 + 6 * i);
+}
+
 // sub-tile culling on the pre-scaled record: 4-bit quadrant mask per (splat, tile)
 extern "C" void hh_quadrant_mask(int n, const float *rec12, const int32_t *tx, const int32_t *ty, uint8_t *out)
 {

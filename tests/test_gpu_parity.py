@@ -383,6 +383,113 @@ def test_api_contract():
     assert np.all(vis.cpu().numpy()[fr.radii > 0])
 
 
+def test_second_backward_follows_autograd_retain_graph_rules():
+    """train.py:106 calls loss.backward() once; like the upstream extension's saved buffers the frame's workspaces live in
+    autograd's saved-tensor slots: backward(retain_graph=True) may be repeated (same gradients, bit for bit), a second
+    backward() without it raises autograd's own error, and a no_grad() render retains nothing and prepares no backward."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import GaussianRasterizer
+    kw = _fixture_kwargs(dict(P=5000, W=256, H=192, D=3, seed=109))
+    rs, inp = _settings(kw), _inputs(kw, True)
+    gimg = S.make_grad_image(256, 192, 9).to(DEV)
+    means2D = torch.zeros(5000, 3, device=DEV, requires_grad=True)
+    color, _ = GaussianRasterizer(rs)(means2D=means2D, **inp)
+    color.backward(gimg, retain_graph=True)
+    g1 = {k: v.grad.clone() for k, v in inp.items()}
+    for v in inp.values():
+        v.grad = None
+    color.backward(gimg)                                  # second pass over the retained graph
+    for k, v in inp.items():
+        assert torch.equal(v.grad, g1[k]), k
+    with pytest.raises(RuntimeError, match="backward through the graph a second time|already been freed"):
+        color.backward(gimg)
+    calls = []
+    orig = dgr.N.backward_prepare
+    dgr.N.backward_prepare = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            c2, _ = GaussianRasterizer(rs)(means2D=means2D, **inp)
+        assert calls == [] and c2.grad_fn is None and torch.equal(c2, color.detach())
+    finally:
+        dgr.N.backward_prepare = orig
+
+
+def test_frozen_parameters_get_no_gradient_with_fused_activations():
+    """The reference's freeze flags (train.py:58-59 --freeze_xyz etc., scene/gaussian_model.py:104-125: the getters detach())
+    with pipe.fused_activations on: the raw-parameter path bypasses the getters, so a model with a freeze flag must take
+    the plain path — the frozen parameter's .grad stays None, single-GPU and through the ShardedRenderer's render()."""
+    from gaussian_params import Pipe
+    from gaussian_renderer import render
+    from scene import GaussianModel
+    W, H = 160, 112
+    cam = S.make_camera(W, H).to(DEV)
+    bg = torch.zeros(3, device=DEV)
+    pipe = Pipe()
+    pipe.fused_activations = True
+    for flag, name in (("freeze_means", "xyz"), ("freeze_scales", "scaling"), ("freeze_opacities", "opacity"), (None, None)):
+        gm = GaussianModel(1)
+        gm.adopt_scene(S.make_scene(3000, W, H, 1, 5, scale_lo=0.01, scale_hi=0.08), device=DEV)
+        if flag:
+            setattr(gm, flag, True)
+        out = render(cam, gm, pipe, bg)
+        out["render"].sum().backward()
+        for k, p in gm._t.items():
+            if k == name:
+                assert p.grad is None, (flag, k)
+            else:
+                assert p.grad is not None and torch.isfinite(p.grad).all(), (flag, k)
+
+
+def test_binning_workspace_is_capped_and_grows_on_demand():
+    """The binning workspace (24 B per instance) is sized for the first depth chunk, not for the upper bound R of all of them.
+    A frame whose lower half stays open (no splats there: those tiles never saturate) needs its later chunks: the first
+    attempt stops with GSR_ERR_WORKSPACE before writing past the workspace, the frame is re-run with room for R, and image
+    and gradients equal a render that had the full workspace from the start, bit for bit.  A saturating frame of the same
+    size stays on the small workspace."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _native as N
+    W, H, P = 640, 368, 150_000
+    scene = S.make_scene(P, W, H, 1, 77, scale_lo=0.01, scale_hi=0.08)
+    cam = S.make_camera(W, H)
+    uneven = S.make_scene(P, W, H, 1, 77, scale_lo=0.01, scale_hi=0.08)
+    uneven.means3D[:, 1] = -uneven.means3D[:, 1].abs() - 0.02 * uneven.means3D[:, 2]          # everything in the upper half
+    gimg = S.make_grad_image(W, H, 3).to(DEV)
+    for name, sc, expect_growth in (("saturating", scene, False), ("upper half only", uneven, True)):
+        kw = raster_kwargs(sc, cam)
+        rs, inp = _settings(kw), _inputs(kw, False)
+        args = (inp["means3D"], inp["shs"], None, inp["opacities"], inp["scales"], inp["rotations"], None, rs)
+        dgr._binning_guess.clear()
+        errors = []
+        orig = N.forward_render
+
+        def spy(*a, **k):
+            try:
+                return orig(*a, **k)
+            except N.GsrError as e:
+                errors.append(e.status)
+                raise
+        N.forward_render = spy
+        try:
+            c1, r1, f1 = dgr.rasterize_forward(*args)
+        finally:
+            N.forward_render = orig
+        s1 = dgr.rasterize_backward_screen(f1, gimg).clone()
+        cap1 = int(f1.plan.binning_capacity)
+        assert f1.plan.num_chunks > 1, (name, f1.plan.num_chunks)
+        if expect_growth:
+            assert errors == [N.ERR_WORKSPACE] and f1.plan.chunks_run > 1 and cap1 == f1.R, (name, errors, f1.plan.chunks_run, cap1, f1.R)
+        else:
+            assert errors == [] and f1.plan.chunks_run == 1 and cap1 < f1.R // 2, (name, errors, cap1, f1.R)
+        # the same frame with the workspace sized for R from the start
+        key = next(iter(dgr._binning_guess))
+        dgr._binning_guess[key] = f1.R
+        c2, r2, f2 = dgr.rasterize_forward(*args)
+        s2 = dgr.rasterize_backward_screen(f2, gimg)
+        assert int(f2.plan.binning_capacity) == f1.R
+        assert torch.equal(c1, c2) and torch.equal(r1, r2) and torch.equal(s1, s2), name
+    dgr._binning_guess.clear()
+
+
 def test_backward_is_bitwise_deterministic():
     kw = _fixture_kwargs(dict(P=5000, W=256, H=192, D=3, seed=109))
     gimg = S.make_grad_image(256, 192, 9).numpy()
@@ -591,6 +698,47 @@ def test_fused_loss_matches_reference_golden():
         lb.backward()
         assert abs(float(la.detach()) - float(lb.detach())) < 5e-6, (Hh, Ww)
         assert (a.grad - a2.grad).abs().max() <= 2e-4 * a2.grad.abs().max(), (Hh, Ww)
+
+
+def test_drop_in_l1_loss_and_ssim_match_reference_golden():
+    """loss_utils.l1_loss / loss_utils.ssim with the reference's signatures (utils/loss_utils.py:17-18, 33-63) as autograd ops
+    over the fused kernels, each on its own against the reference's values and autograd gradients (tests/golden/loss.npz:
+    l1_*, ssim_*, grad_l1_a*, grad_ssim_a*), then composed exactly as train.py:104-105 writes the loss."""
+    import loss_utils
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "loss.npz"))
+    for i in range(2):
+        b = torch.tensor(gold[f"b{i}"], device=DEV)
+        a = torch.tensor(gold[f"a{i}"], device=DEV, requires_grad=True)
+        l1 = loss_utils.l1_loss(a, b)
+        assert isinstance(l1.grad_fn, loss_utils._L1._backward_cls) or "L1" in type(l1.grad_fn).__name__
+        assert abs(float(l1) - float(gold[f"l1_{i}"])) < 1e-6
+        l1.backward()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), gold[f"grad_l1_a{i}"], atol=1e-9, rtol=1e-5)
+        a = torch.tensor(gold[f"a{i}"], device=DEV, requires_grad=True)
+        s = loss_utils.ssim(a, b)
+        assert abs(float(s) - float(gold[f"ssim_{i}"])) < 2e-6
+        (s * 1.0).backward()
+        np.testing.assert_allclose(a.grad.cpu().numpy(), gold[f"grad_ssim_a{i}"], atol=3e-9, rtol=3e-4)
+        # train.py:104-105 verbatim; the two calls share one fused forward
+        a = torch.tensor(gold[f"a{i}"], device=DEV, requires_grad=True)
+        Ll1 = loss_utils.l1_loss(a, b)
+        assert loss_utils._shared is not None and loss_utils._shared[0] is a
+        loss = (1.0 - 0.2) * Ll1 + 0.2 * (1.0 - loss_utils.ssim(a, b))
+        assert loss_utils._shared is None
+        loss.backward()
+        assert abs(float(loss) - float(gold[f"loss_{i}"])) < 2e-6
+        np.testing.assert_allclose(a.grad.cpu().numpy(), gold[f"grad_a{i}"], atol=2e-9, rtol=2e-4)
+        # an in-place change of the image between the two calls must not be served from the shared forward
+        a2 = torch.tensor(gold[f"a{i}"], device=DEV)
+        v1 = float(loss_utils.l1_loss(a2, b))
+        a2.mul_(0.5)
+        s2 = float(loss_utils.ssim(a2, b))
+        assert abs(s2 - float(loss_utils.ssim_torch(a2, b))) < 2e-6 and abs(v1 - float(gold[f"l1_{i}"])) < 1e-6
+    # other signatures fall back to the torch form: window sizes, per-image means, batches, CPU tensors
+    a, b = torch.rand(2, 3, 20, 24, device=DEV), torch.rand(2, 3, 20, 24, device=DEV)
+    assert loss_utils.ssim(a, b, size_average=False).shape == (2,)
+    assert abs(float(loss_utils.ssim(a[0], b[0], window_size=7)) - float(loss_utils.ssim_torch(a[0], b[0], 7))) < 1e-7
+    assert abs(float(loss_utils.l1_loss(a.cpu(), b.cpu())) - float((a - b).abs().mean())) < 1e-6
 
 
 def test_cfg3_full_size_vs_oracle():

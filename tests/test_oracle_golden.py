@@ -100,3 +100,61 @@ def test_oracle_projection_matches_reference_point_transform():
         assert not np.any(vis & (view[:, 2] < 0.19))
         checked += int(vis.sum())
     assert checked > 20
+
+
+def test_cov3d_matches_reference_build_scaling_rotation():
+    """A.3 pinned by the reference's own functions (tests/golden/cov3d.npz from utils/general_utils.py:64-110 and the
+    covariance builder of scene/gaussian_model.py:25-29): quaternion -> R, Sigma = (R S)(R S)^T, packing
+    [xx, xy, xz, yy, yz, zz] — against the oracle's cov3D (both precisions), the product's gsr_math.h (through the
+    g++ harness) and the host-side GaussianModel / GaussianParams.get_covariance."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+
+    import torch
+    gold = np.load(os.path.join(G, "cov3d.npz"))
+    q_raw, s = gold["rotation"].astype(np.float64), gold["scaling"].astype(np.float64)
+    qn = q_raw / np.linalg.norm(q_raw, axis=1, keepdims=True)          # the caller normalises (scene/gaussian_model.py:106-109)
+    P = qn.shape[0]
+    cam = S.make_camera(64, 64)
+    means = np.tile([0.0, 0.0, 3.0], (P, 1)) + np.random.default_rng(0).normal(0, 0.2, (P, 3))
+    for j, mod in enumerate(gold["modifiers"]):
+        want = gold[f"cov6_{j}"].astype(np.float64)
+        for dtype, tol in ((np.float64, 2e-6), (np.float32, 2e-6)):      # the golden itself is the reference's float32 result
+            fr = oracle.rasterize(dtype=dtype, image_height=64, image_width=64, tanfovx=0.5, tanfovy=0.5, bg=np.zeros(3),
+                                  scale_modifier=float(mod), viewmatrix=cam.world_view_transform.numpy(),
+                                  projmatrix=cam.full_proj_transform.numpy(), sh_degree=0, campos=np.zeros(3), means3D=means,
+                                  opacities=np.full((P, 1), 0.5), colors_precomp=np.full((P, 3), 0.5), scales=s, rotations=qn)
+            vis = fr.radii > 0
+            assert vis.sum() > P // 2
+            scale = np.abs(want[vis]).max(1, keepdims=True)
+            assert (np.abs(fr.cov3D[vis] - want[vis]) <= tol * scale + 1e-12).all()
+        # host-side builders (torch): util.cov3d_from (used by the parity tests), GaussianParams / GaussianModel.get_covariance
+        from util import cov3d_from
+        got = cov3d_from(torch.tensor(s, dtype=torch.float32), torch.tensor(qn, dtype=torch.float32), float(mod)).numpy()
+        assert (np.abs(got - want) <= 3e-6 * np.abs(want).max(1, keepdims=True) + 1e-12).all()
+        from scene import GaussianModel
+        gm = GaussianModel(0)
+        gm._t["scaling"] = torch.log(torch.tensor(s, dtype=torch.float32))
+        gm._t["rotation"] = torch.tensor(q_raw, dtype=torch.float32)   # raw: the model's getter path normalises like build_rotation
+        got = gm.get_covariance(float(mod)).numpy()
+        assert (np.abs(got - want) <= 5e-6 * np.abs(want).max(1, keepdims=True) + 1e-12).all()
+    # rotation matrices and the un-packed L = R S
+    r, x, y, z = qn.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                  2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(P, 3, 3)
+    np.testing.assert_allclose(R, gold["R"], atol=2e-6)
+    np.testing.assert_allclose(R * s[:, None, :], gold["L_0"], rtol=1e-5, atol=1e-7 * float(np.abs(gold["L_0"]).max()))      # float32 golden
+    # the product's header, compiled for the host
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as d:
+        so = os.path.join(d, "libhh.so")
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-o", so, os.path.join(here, "host_harness.cpp")])
+        hh = C.CDLL(so)
+        out = np.zeros((P, 6), np.float32)
+        s32, q32 = np.ascontiguousarray(s, np.float32), np.ascontiguousarray(qn, np.float32)
+        for j, mod in enumerate(gold["modifiers"]):
+            hh.hh_cov3d(P, s32.ctypes.data_as(C.c_void_p), q32.ctypes.data_as(C.c_void_p), C.c_float(float(mod)),
+                        out.ctypes.data_as(C.c_void_p))
+            want = gold[f"cov6_{j}"]
+            assert (np.abs(out - want) <= 3e-6 * np.abs(want).max(1, keepdims=True) + 1e-12).all()
