@@ -443,12 +443,11 @@ def _traffic_from_profiles(kernel):
 
 def _valu_roofline(kernel, launch_ms, workload):
     """VALU-issue roofline of the dominant (blend) kernel.  Inputs, both committed under profiles/ and measured on MI355X:
-      * valu_microbench/r02_valu_rates.json — wave-instructions per cycle per SIMD for each instruction class at 4
-        resident waves per SIMD (profiles/valu_microbench/valu_microbench.hip), i.e. the issue cycles one wave64
-        instruction of that class occupies its SIMD;
-      * r02_valu_mix.json — for the default cfg3 run: the kernel's VALU wave-instructions per launch (rocprofv3 PMC
-        SQ_INSTS_VALU) and the share of each class (static count over the blend loop's disassembly), made by
-        profiles/valu_mix.py.
+      * valu_microbench/r02_valu_rates.json — issue cycles one wave64 instruction of each class costs its SIMD at
+        saturation (profiles/valu_microbench/valu_microbench.hip: v_mul/add 2.2, v_fma 3.6, packed fp32 / compares /
+        selects / min / max / DPP 4.1-4.2, transcendentals 8.1 cycles);
+      * r02_valu_mix.json — for the default cfg3 run: the kernel's VALU wave-instructions per launch by class (rocprofv3
+        PMC SQ_INSTS_VALU_* + the packed share of each class from the disassembly), made by profiles/valu_mix.py.
     required = sum over classes of instructions x issue cycles; available = SIMDs x cycles of the launch.
     `frac` = required / available: 1.0 would mean every SIMD issues a VALU instruction on every cycle of the launch."""
     rates, mix = _profiles_json("valu_microbench/r02_valu_rates.json"), _profiles_json("r02_valu_mix.json")
@@ -457,13 +456,15 @@ def _valu_roofline(kernel, launch_ms, workload):
     k = mix["kernels"][kernel]
     clock_hz = float(rates.get("clock_hz", 2.4e9))
     simds = int(rates.get("simds", 1024))
-    cyc = {name: 1.0 / r["w4"]["per_cycle_per_simd"] for name, r in rates["rates"].items() if r.get("w4", {}).get("per_cycle_per_simd")}
-    required = sum(k["insts_valu"] * share * cyc.get(cls, cyc.get("v_fma_f32", 2.0)) for cls, share in k["class_share"].items())
+    cyc = {name: r["cycles_per_instruction"] for name, r in rates["rates"].items()}
+    required = sum(k["insts_valu"] * share * cyc.get(cls, cyc["v_fma_f32"]) for cls, share in k["class_share"].items())
     available = simds * launch_ms * 1e-3 * clock_hz
     return {"kernel": kernel, "unit": "VALU issue cycles per launch", "achieved": int(required), "peak": int(available),
             "frac": round(required / available, 4), "insts_valu_per_launch": int(k["insts_valu"]),
             "clock_hz": clock_hz, "class_share": k["class_share"],
-            "issue_cycles_per_class": {c: round(cyc[c], 3) for c in k["class_share"] if c in cyc}}
+            "issue_cycles_per_class": {c: cyc[c] for c in k["class_share"] if c in cyc},
+            "note": "peak assumes the microbenchmark's clock; the blend kernels also issue LDS reads, scalar branches and "
+                    "s_waitcnt on the same SIMD"}
 
 
 def _cpu_baseline(workload):

@@ -63,6 +63,12 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(-(-n // step) * step, dtype=torch.uint8, device=device)
 
 
+def _binning_bytes(n: int) -> int:
+    """gsr_binning_size(desc, n) without the call: six u32 arrays of max(n, 1) entries, each padded to 256 bytes
+    (csrc/gsr_binning.hip carve_binning; tests/test_abi.py holds the two together)."""
+    return 6 * ((4 * max(int(n), 1) + 255) // 256 * 256)
+
+
 _binning_guess = {}        # (P, W, H, slab, device) -> instances the binning workspace of that frame shape last had to hold
 
 
@@ -129,25 +135,30 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
             color = (torch.empty if tile_rows is None else torch.zeros)(3, H, W, dtype=torch.float32, device=device)
         guess_key = (P, W, H, None if tile_rows is None else tuple(int(v) for v in tile_rows), device.index)
         guess = _binning_guess.get(guess_key, 0)
-        binning = _workspace(N.binning_size(fr.desc, guess), device) if guess > 0 else None
-        fr.plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device, image_ws=fr.image_ws)
+        binning = _workspace(_binning_bytes(guess), device) if guess > 0 else None
+        fr.plan = plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device, image_ws=fr.image_ws)
         # The binning workspace (24 B per instance) is sized for what the FIRST depth chunk can emit, not for the upper bound R
         # of every chunk (11.8 GB at 5e6 Gaussians / 4K): frames whose tiles saturate never get past that chunk.  A frame that
         # does need more stops with GSR_ERR_WORKSPACE before it writes anything it has no room for, and is re-run once with a
-        # workspace for R; frames of that shape then start with R.
-        capacity = max(min(N.binning_first_chunk_capacity(fr.plan), fr.R), min(guess, fr.R))
+        # workspace for R; frames of that shape then start with R.  (Plain arithmetic here, no library calls: the stream is
+        # idle between the plan readback and the first launch of stage 2.)
+        R = int(plan.num_rendered)
+        first = int(plan.chunk_instances_max[0])
+        capacity = min(first + first // 4 + (1 << 20), R) if plan.num_chunks > 1 else R        # = gsr_binning_first_chunk_capacity
+        capacity = max(capacity, min(guess, R))
         while True:
-            if binning is None or binning.numel() < N.binning_size(fr.desc, capacity):
-                binning = _workspace(N.binning_size(fr.desc, capacity), device)
-            fr.plan.binning_capacity = capacity
+            need = _binning_bytes(capacity)
+            if binning is None or binning.numel() < need:
+                binning = _workspace(need, device)
+            plan.binning_capacity = capacity
             fr.binning_ws = binning
             try:
-                N.forward_render(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan, color, device)
+                N.forward_render(fr.desc, fr.cam, fr.gauss, fr.geom_ws, binning, fr.image_ws, plan, color, device)
                 break
             except N.GsrError as e:
-                if e.status != N.ERR_WORKSPACE or capacity >= fr.R:
+                if e.status != N.ERR_WORKSPACE or capacity >= R:
                     raise
-                capacity, binning = fr.R, None
+                capacity, binning = R, None
         _binning_guess[guess_key] = capacity
         if len(_binning_guess) > 64:
             _binning_guess.pop(next(iter(_binning_guess)))

@@ -84,3 +84,19 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libgsr_oracle" not in src, f
+
+
+def test_python_mirror_of_binning_size_matches_the_library():
+    """diff_gaussian_rasterization._binning_bytes / the first-chunk capacity rule are evaluated in Python between the plan
+    readback and the first launch of stage 2 (no ctypes round trips while the stream idles): they must equal the C ABI's."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _native as N
+    desc = N.make_desc(1000, 3, 16, 640, 480, 0.5, 0.5, 1.0, False, False)
+    for n in (0, 1, 63, 64, 65, 1000, 123_457, 28_201_899, 492_421_683):
+        assert dgr._binning_bytes(n) == N.binning_size(desc, n), n
+    plan = N.FramePlan()
+    for chunks, first, R in ((1, 500, 500), (3, 2_000_000, 28_000_000), (2, 900_000, 1_000_000), (4, 10, 5_000_000_000)):
+        plan.num_chunks, plan.num_rendered = chunks, R
+        plan.chunk_instances_max[0] = first
+        want = min(first + first // 4 + (1 << 20), R) if chunks > 1 else R
+        assert N.binning_first_chunk_capacity(plan) == want
