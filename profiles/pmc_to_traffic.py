@@ -54,7 +54,7 @@ def main():
         traffic[k] = int(fb + wb)
     with open(os.path.join(outdir, "traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
-    with open(os.path.join(outdir, "r01_pmc_traffic_detail.json"), "w") as f:
+    with open(os.path.join(outdir, "r02_pmc_traffic_detail.json"), "w") as f:
         json.dump(detail, f, indent=1)
     print(json.dumps(detail, indent=1))
 

@@ -58,7 +58,7 @@ def isa_counts(path):
             t = line.strip().split()
             if t and t[0].startswith("v_"):
                 mn = t[0]
-                if "row_shr" in line or "row_bcast" in line or "quad_perm" in line:
+                if ("row_shr" in line or "row_bcast" in line or "quad_perm" in line) and not mn.endswith("_dpp"):
                     mn += "_dpp"
                 out[cur][mn] += 1
     return out
@@ -88,18 +88,22 @@ def mix(pmc_csv, isa_path, out_path):
             return a / (a + b) if a + b else 0.0
         s_fma = pk_share(["v_pk_fma_f32"], ["v_fma_f32", "v_fmac_f32", "v_mad_f32", "v_fma_f32_dpp"])
         s_mul = pk_share(["v_pk_mul_f32"], ["v_mul_f32", "v_mul_f32_e32", "v_mul_f32_e64"])
-        s_add = pk_share(["v_pk_add_f32"], ["v_add_f32", "v_sub_f32", "v_subrev_f32", "v_add_f32_e32", "v_sub_f32_e32", "v_add_f32_e64"])
+        plain_add = ["v_add_f32", "v_sub_f32", "v_subrev_f32", "v_add_f32_e32", "v_sub_f32_e32", "v_subrev_f32_e32", "v_add_f32_e64", "v_sub_f32_e64"]
+        n_dpp = n.get("v_add_f32_dpp", 0)
+        n_add_all = n.get("v_pk_add_f32", 0) + sum(n.get(m, 0) for m in plain_add) + n_dpp
+        s_add = n.get("v_pk_add_f32", 0) / n_add_all if n_add_all else 0.0
+        s_dpp = n_dpp / n_add_all if n_add_all else 0.0       # the wave reduction's DPP adds are counted as ADD_F32 too
         movs = sum(c for m, c in n.items() if m.startswith("v_mov") or m.startswith("v_accvgpr"))
         others_static = sum(c for m, c in n.items() if re.match(r"v_(cmp|cndmask|min|max|med3|mov|readlane|readfirstlane|and|or|lshl|bfe|add_f32_dpp)", m)) or 1
         s_mov = min(movs / others_static, 1.0)
         counts = {
             "v_pk_fma_f32": fma * s_fma, "v_fma_f32": fma * (1 - s_fma), "v_pk_mul_f32": mul * s_mul, "v_mul_f32": mul * (1 - s_mul),
-            "v_pk_add_f32": add * s_add, "v_add_f32": add * (1 - s_add), "v_exp_f32": trans, "v_mov_b32": other * s_mov + i32 + cvt,
+            "v_pk_add_f32": add * s_add, "v_add_f32_dpp": add * s_dpp, "v_add_f32": add * (1 - s_add - s_dpp), "v_exp_f32": trans, "v_mov_b32": other * s_mov + i32 + cvt,
             "v_cndmask_b32(sgpr)": other * (1 - s_mov),       # compares, selects, min/max, DPP adds: 4.2-cycle class
         }
         out["kernels"][key] = {"insts_valu": tot, "launches_sampled": len(ctr.get("SQ_INSTS_VALU", [])) - SKIP_FIRST,
                                "pmc_per_launch": {k: round(v) for k, v in avg.items()},
-                               "static_packed_share": {"fma": round(s_fma, 3), "mul": round(s_mul, 3), "add": round(s_add, 3), "mov_of_other": round(s_mov, 3)},
+                               "static_packed_share": {"fma": round(s_fma, 3), "mul": round(s_mul, 3), "add": round(s_add, 3), "dpp_of_add": round(s_dpp, 3), "mov_of_other": round(s_mov, 3)},
                                "class_share": {k: round(v / tot, 4) if tot else 0.0 for k, v in counts.items()}}
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))
