@@ -90,11 +90,34 @@ def _camera(rs: GaussianRasterizationSettings, device):
     return N.Camera(N._ptr(bg), N._ptr(vm), N._ptr(pm), N._ptr(cp)), (bg, vm, pm, cp)
 
 
+# torch.autograd.Function.forward runs with grad mode OFF, so "will a backward follow?" must be asked by the public entry
+# points BEFORE they call .apply(): they leave the caller's grad mode here (thread-local: the library is re-entrant).
+import threading as _threading
+
+_tls = _threading.local()
+
+
+def _apply(fn, *args):
+    _tls.caller_grad = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _tls.caller_grad = None
+
+
+def caller_grad_enabled() -> bool:
+    g = getattr(_tls, "caller_grad", None)
+    return torch.is_grad_enabled() if g is None else g
+
+
 def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                      rs: GaussianRasterizationSettings, tile_rows=None, out_color=None, sh_rest=None, raw=False):
+                      rs: GaussianRasterizationSettings, tile_rows=None, out_color=None, sh_rest=None, raw=False,
+                      prepare_needs=None):
     """Stage 1 + stage 2 of the native forward.  Returns (color, radii, frame).
     raw=True: the tensors are the parameter store's RAW values (sh = _features_dc, sh_rest = _features_rest,
-    opacities = logits, scales = log-scales, rotations = unnormalised) and the activations run in the kernels."""
+    opacities = logits, scales = log-scales, rotations = unnormalised) and the activations run in the kernels.
+    prepare_needs: which gradients a backward will want (as rasterize_backward_geom's `needs`), when one will follow: the
+    backward's output tensors are then allocated up front, while the host waits for the plan anyway."""
     device = means3D.device
     if device.type != "cuda":
         raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a HIP device; "
@@ -136,7 +159,14 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
         guess_key = (P, W, H, None if tile_rows is None else tuple(int(v) for v in tile_rows), device.index)
         guess = _binning_guess.get(guess_key, 0)
         binning = _workspace(_binning_bytes(guess), device) if guess > 0 else None
+        early = None
+        if prepare_needs is not None and P > 0 and any(prepare_needs) and caller_grad_enabled():
+            needs = tuple(bool(x) for x in prepare_needs)
+            early = (needs,) + _alloc_grads(fr, needs, torch.empty) + (torch.empty(P, N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=device),)
         fr.plan = plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device, image_ws=fr.image_ws)
+        if early is not None:          # handed to the backward; prepare_backward() zero-fills them on sparse frames
+            needs, tensors, grads, screen = early
+            fr.pre = {"needs": needs, "tensors": tensors, "grads": grads, "screen": screen}
         # The binning workspace (24 B per instance) is sized for what the FIRST depth chunk can emit, not for the upper bound R
         # of every chunk (11.8 GB at 5e6 Gaussians / 4K): frames whose tiles saturate never get past that chunk.  A frame that
         # does need more stops with GSR_ERR_WORKSPACE before it writes anything it has no room for, and is re-run once with a
@@ -169,11 +199,10 @@ def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.T
     """K7 + deterministic per-Gaussian reduction -> screen-space gradients [P, 12]."""
     P = fr.desc.P
     grad_color = _f32c(grad_color, fr.device)
-    pre_screen = fr.pre.pop("screen", None) if fr.pre is not None else None        # zero-filled after the forward; used once
-    screen = pre_screen if pre_screen is not None else torch.empty(max(P, 1), N.SCREEN_GRAD_STRIDE, dtype=torch.float32,
-                                                                   device=fr.device)
-    if pre_screen is None:
-        fr.plan.screen_prezeroed = 0
+    screen = fr.pre.pop("screen", None) if fr.pre is not None else None        # allocated (and, on sparse frames, zero-filled) by the forward
+    if screen is None:
+        screen = torch.empty(max(P, 1), N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=fr.device)
+        fr.plan.screen_prezeroed = 0            # (set only by prepare_backward(), for the very tensor it filled)
     if grad_color is None:
         return screen.zero_()[:P]
     with torch.cuda.device(fr.device):
@@ -204,19 +233,25 @@ def _alloc_grads(fr: "_Frame", needs, alloc):
 def prepare_backward(fr: "_Frame", needs) -> None:
     """Called right after the forward when a backward will follow: the stream is idle while the host walks back
     through the caller's code to the loss, so the backward's zero fills (screen-space gradients + the parameter
-    gradients of the sparse geometry backward, ~280 MB at 1e6 Gaussians) are enqueued NOW, in one launch."""
+    gradients of the sparse geometry backward, ~280 MB at 1e6 Gaussians) are enqueued NOW, in one launch, into the
+    tensors the forward allocated up front (rasterize_forward(prepare_needs=...)) or into fresh ones.
+    (Measured and dropped: the same fill on a second stream beside the stage-2 kernels or beside k_render_bwd — the
+    fill takes 65-86 us instead of 53 and the kernels it runs beside slow down by as much: no step time is gained.)"""
     P, plan = fr.desc.P, fr.plan
     # ctx.needs_input_grad stays True for leaf parameters under torch.no_grad() (eval / test-view renders): no backward can follow
-    if P == 0 or plan.num_rendered <= 0 or plan.chunks_run <= 0 or not any(needs) or not torch.is_grad_enabled():
+    if P == 0 or plan.num_rendered <= 0 or plan.chunks_run <= 0 or not any(needs) or not caller_grad_enabled():
         return
     if int(plan.chunk_rank_begin[plan.chunks_run]) * 4 >= P:
         return                                  # the dense geometry backward writes every row itself
     needs = tuple(bool(x) for x in needs)
-    tensors, grads = _alloc_grads(fr, needs, torch.empty)
-    screen = torch.empty(P, N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=fr.device)
+    if fr.pre is None or fr.pre["needs"] != needs:
+        tensors, grads = _alloc_grads(fr, needs, torch.empty)
+        fr.pre = {"needs": needs, "tensors": tensors, "grads": grads,
+                  "screen": torch.empty(P, N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=fr.device)}
+    if fr.pre["grads"].prezeroed:
+        return
     with torch.cuda.device(fr.device):
-        N.backward_prepare(fr.desc, fr.gauss, plan, screen, grads, fr.device)
-    fr.pre = {"needs": needs, "tensors": tensors, "grads": grads, "screen": screen}
+        N.backward_prepare(fr.desc, fr.gauss, plan, fr.pre["screen"], fr.pre["grads"], fr.device)
 
 
 def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int = 0, g1: Optional[int] = None,
@@ -300,8 +335,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise
         else:
-            color, radii, frame = rasterize_forward(*args, rs)
-            prepare_backward(frame, tuple(ctx.needs_input_grad[:8]))
+            color, radii, frame = rasterize_forward(*args, rs, prepare_needs=tuple(ctx.needs_input_grad[:8]))
+            prepare_backward(frame, tuple(ctx.needs_input_grad[:8]))       # frames the early path did not take (single chunk)
         _stash_frame(ctx, frame)
         ctx.raster_settings = rs
         ctx.shapes = (means2D.shape, opacities.shape)
@@ -346,12 +381,13 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_logits, log_scales, raw_rotations, raster_settings):
         rs = raster_settings
+        n = ctx.needs_input_grad       # xyz, means2D, f_dc, f_rest, opacity, scales, rotations
+        needs = (n[0], n[1], n[2], False, n[4], n[5], n[6], False, n[3])
         color, radii, frame = rasterize_forward(xyz, features_dc, None, opacity_logits, log_scales, raw_rotations, None, rs,
-                                                sh_rest=features_rest, raw=True)
+                                                sh_rest=features_rest, raw=True, prepare_needs=None if rs.debug else needs)
         if rs.debug:
             torch.cuda.synchronize(xyz.device)
-        n = ctx.needs_input_grad       # xyz, means2D, f_dc, f_rest, opacity, scales, rotations
-        prepare_backward(frame, (n[0], n[1], n[2], False, n[4], n[5], n[6], False, n[3]))
+        prepare_backward(frame, needs)
         _stash_frame(ctx, frame)
         ctx.shapes = (means2D.shape, opacity_logits.shape)
         ctx.mark_non_differentiable(radii)
@@ -374,8 +410,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+    return _apply(_RasterizeGaussians, means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                  cov3Ds_precomp, raster_settings)
 
 
 # ---- opt-in: fuse the reference's getters without touching the caller -------------------------------------------
@@ -489,7 +525,7 @@ class GaussianRasterizer(nn.Module):
             leaves = _match_getters(means3D, opacities, shs, scales, rotations)
             if leaves is not None:
                 xyz, dc, rest, op, sc, rot = leaves
-                return _RasterizeGaussiansRaw.apply(xyz, means2D, dc, rest, op, sc, rot, rs)
+                return _apply(_RasterizeGaussiansRaw, xyz, means2D, dc, rest, op, sc, rot, rs)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, rs)
 
@@ -502,5 +538,4 @@ class GaussianRasterizer(nn.Module):
         rs = rs._replace(sh_degree=int(rs.sh_degree), image_height=int(rs.image_height), image_width=int(rs.image_width))
         if features_rest is None or features_rest.numel() == 0:
             features_rest = torch.empty(0, dtype=torch.float32, device=xyz.device)
-        return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_logits, log_scales,
-                                            raw_rotations, rs)
+        return _apply(_RasterizeGaussiansRaw, xyz, means2D, features_dc, features_rest, opacity_logits, log_scales, raw_rotations, rs)

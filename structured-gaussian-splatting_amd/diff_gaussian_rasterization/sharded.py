@@ -203,7 +203,8 @@ class _ShardedRasterize(torch.autograd.Function):
             mine[0, :n_words].view(3, rows_max, W)[:, :y1 - y0] = full[:, y0:y1]
         needs = tuple(ctx.needs_input_grad[:8]) + ((bool(ctx.needs_input_grad[10]),) if raw else ())
         ctx.needs = needs
-        want_prefix = shard.backward_mode == "allreduce_screen" and any(needs) and torch.is_grad_enabled()
+        from . import caller_grad_enabled          # Function.forward itself runs with grad mode off
+        want_prefix = shard.backward_mode == "allreduce_screen" and any(needs) and caller_grad_enabled()
         order, n_mine = backend.binned_prefix(frame) if want_prefix else (None, 0)
         mine[0, n_words].fill_(float(int(n_mine) >> 16))
         mine[0, n_words + 1].fill_(float(int(n_mine) & 0xFFFF))
@@ -356,10 +357,11 @@ class ShardedRenderer:
             raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         e = torch.empty(0, dtype=torch.float32, device=means3D.device)
         rs = rs._replace(sh_degree=int(rs.sh_degree))
-        return _ShardedRasterize.apply(means3D, means2D, e if shs is None else shs,
-                                       e if colors_precomp is None else colors_precomp, opacities,
-                                       e if scales is None else scales, e if rotations is None else rotations,
-                                       e if cov3D_precomp is None else cov3D_precomp, rs, self)
+        from . import _apply
+        return _apply(_ShardedRasterize, means3D, means2D, e if shs is None else shs,
+                      e if colors_precomp is None else colors_precomp, opacities,
+                      e if scales is None else scales, e if rotations is None else rotations,
+                      e if cov3D_precomp is None else cov3D_precomp, rs, self)
 
     def render(self, viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None):
         import math
@@ -383,8 +385,9 @@ class ShardedRenderer:
                 and isinstance(self.backend, NativeBackend) and not frozen):      # frozen parameters: the getters' detach() must run
             rs = rs._replace(sh_degree=int(rs.sh_degree))
             e = torch.empty(0, dtype=torch.float32, device=xyz.device)
-            image, radii = _ShardedRasterize.apply(pc._xyz, screenspace_points, pc._features_dc, e, pc._opacity, pc._scaling,
-                                                   pc._rotation, e, rs, self, pc._features_rest)
+            from . import _apply
+            image, radii = _apply(_ShardedRasterize, pc._xyz, screenspace_points, pc._features_dc, e, pc._opacity, pc._scaling,
+                                  pc._rotation, e, rs, self, pc._features_rest)
             return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
         scales = rotations = cov = None
         if pipe.compute_cov3D_python:

@@ -410,6 +410,16 @@ def test_second_backward_follows_autograd_retain_graph_rules():
         with torch.no_grad():
             c2, _ = GaussianRasterizer(rs)(means2D=means2D, **inp)
         assert calls == [] and c2.grad_fn is None and torch.equal(c2, color.detach())
+        # ... and with grad mode on, a depth-complex frame (its first chunk holds < P/4 Gaussians) gets its backward outputs
+        # zero-filled early, once
+        scene, cam = S.make_scene(60_000, 320, 200, 1, 5, scale_lo=0.02, scale_hi=0.2), S.make_camera(320, 200)
+        kw2 = raster_kwargs(scene, cam)
+        rs2, inp2 = _settings(kw2), _inputs(kw2, True)
+        m2 = torch.zeros(60_000, 3, device=DEV, requires_grad=True)
+        c3, _ = GaussianRasterizer(rs2)(means2D=m2, **inp2)
+        assert calls == [1], calls
+        c3.sum().backward()
+        assert calls == [1] and all(torch.isfinite(v.grad).all() for v in inp2.values())
     finally:
         dgr.N.backward_prepare = orig
 
