@@ -321,7 +321,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         if ((rc = launch_chunk_binning(f, c, r0, r1, (uint64_t)plan->chunk_instances_max[c], emitted_before, gw, bw, iw, &sort_result,
                                        dbg, s)))
             return rc;
-        if ((rc = launch_chunk_colors(f, *cam, *g, r0, r1, gw, dbg, s))) return rc;      // A.6 for this chunk's Gaussians only
+        if ((rc = launch_chunk_colors(f, *cam, *g, r0, r1, plan->num_visible, gw, dbg, s))) return rc;      // A.6 for this chunk's Gaussians only
         if ((rc = launch_render_fwd(f, *cam, c, last, gw, bw, iw, out_color, dbg, s))) return rc;
         plan->chunks_run = c + 1;
         plan->instances_emitted = -1;                 // the last chunk's count stays on the device

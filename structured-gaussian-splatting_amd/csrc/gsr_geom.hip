@@ -163,8 +163,22 @@ __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors(FrameK f, int r0, i
         for (int k = 3; k < 3 * K; ++k) shl[k] = rest[k - 3];
     } else {
         const float *src = shs + (size_t)i * f.M * 3;
+        if constexpr ((3 * K) % 4 == 0) {
+            if ((f.M * 3) % 4 == 0) {              // the row starts on a 16-byte boundary: a gathered row is 12 x 16 B, not 48 x 4 B
+                const float4 *src4 = reinterpret_cast<const float4 *>(src);
 #pragma unroll
-        for (int k = 0; k < 3 * K; ++k) shl[k] = src[k];
+                for (int k = 0; k < 3 * K / 4; ++k) {
+                    const float4 v = src4[k];
+                    shl[4 * k] = v.x; shl[4 * k + 1] = v.y; shl[4 * k + 2] = v.z; shl[4 * k + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3 * K; ++k) shl[k] = src[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3 * K; ++k) shl[k] = src[k];
+        }
     }
     float rgb[3];
     unsigned cl;
@@ -174,11 +188,106 @@ __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors(FrameK f, int r0, i
     clamped[i] = (uint8_t)cl;
 }
 
-int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, GeomWS &ws, bool debug,
-                        hipStream_t s)
+// The same for a chunk that holds EVERY visible Gaussian (a frame that does not saturate: one chunk): Gaussians are taken in
+// index order, so a wave's 64 coefficient rows are one contiguous run, loaded with full 16-byte-per-lane coalescing into
+// LDS rows (a gather by depth rank reads 192-byte rows scattered over the tensor).  Invisible Gaussians (zeroed record)
+// are skipped.
+template <int DEG, bool RAW>
+__global__ __launch_bounds__(kGeomBlock) void k_chunk_colors_all(FrameK f, const float *__restrict__ campos, const float *__restrict__ means,
+                                                                 const float *__restrict__ shs, const float *__restrict__ shs_rest,
+                                                                 float4 *__restrict__ records, uint8_t *__restrict__ clamped)
+{
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    constexpr int kRow = 3 * K + 1;                            // +1: lanes read their rows conflict-free
+    __shared__ float sh_stage[(kGeomBlock / 64) * 64 * kRow];
+    const int i = blockIdx.x * kGeomBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave_first = i - lane;
+    const int n_rows = min(64, f.P - wave_first);
+    if (n_rows <= 0) return;
+    const bool visible = i < f.P && reinterpret_cast<const float *>(records + 3 * (size_t)i)[9] > 0.f;      // record.depth
+    if (__ballot(visible) == 0ull) return;
+    float *stage = sh_stage + wv * (64 * kRow);
+    const int rowf = 3 * f.M;                                  // stored floats per Gaussian (>= 3 K)
+    if constexpr (RAW) {
+        for (int e = lane; e < n_rows * 3; e += 64) stage[(e / 3) * kRow + e % 3] = shs[(size_t)wave_first * 3 + e];
+        if constexpr (K > 1) {
+            const int row = rowf - 3;
+            const float *src = shs_rest + (size_t)wave_first * row;
+            for (int e = lane; e < n_rows * row; e += 64) {
+                const int c = e % row;
+                if (c < 3 * K - 3) stage[(e / row) * kRow + 3 + c] = src[e];
+            }
+        }
+    } else {
+        const float *src = shs + (size_t)wave_first * rowf;
+        const int total = n_rows * rowf;
+        if ((((uintptr_t)src) & 15) == 0 && rowf % 4 == 0) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(src);
+            for (int e4 = lane; e4 < total / 4; e4 += 64) {
+                const float4 v = src4[e4];
+                const int e = 4 * e4, r = e / rowf, c = e - r * rowf;          // rowf % 4 == 0: the four floats share a row
+                if (c < 3 * K) {                                               // (3 K) % 4 == 0 whenever K > 1; K == 1 has rowf % 4 != 0 unless M % 4 == 0
+                    float *d = stage + r * kRow + c;
+                    d[0] = v.x;
+                    if (c + 1 < 3 * K) d[1] = v.y;
+                    if (c + 2 < 3 * K) d[2] = v.z;
+                    if (c + 3 < 3 * K) d[3] = v.w;
+                }
+            }
+        } else {
+            for (int e = lane; e < total; e += 64) {
+                const int r = e / rowf, c = e - r * rowf;
+                if (c < 3 * K) stage[r * kRow + c] = src[e];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (!visible) return;
+    const float cp[3] = {campos[0], campos[1], campos[2]};
+    const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    float shl[3 * K];
+#pragma unroll
+    for (int k = 0; k < 3 * K; ++k) shl[k] = stage[lane * kRow + k];
+    float rgb[3];
+    unsigned cl;
+    sh_color_one<DEG>(f, cp, p, shl, rgb, cl);
+    float *rec = reinterpret_cast<float *>(records + 3 * (size_t)i);
+    rec[6] = rgb[0]; rec[7] = rgb[1]; rec[8] = rgb[2];
+    clamped[i] = (uint8_t)cl;
+}
+
+int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, int num_visible, GeomWS &ws,
+                        bool debug, hipStream_t s)
 {
     if (!g.shs || r1 <= r0) return GSR_OK;           // precomputed colours went into the records in the preprocess
     ProfileScope prof("chunk_colors", s);
+    if (r0 == 0 && r1 >= num_visible && (long long)num_visible * 2 >= (long long)f.P) {
+        // the chunk is every visible Gaussian and most Gaussians are visible: walk the tensor in index order
+        const int grid_all = (f.P + kGeomBlock - 1) / kGeomBlock;
+#define GSR_CA(DEG, RAW)                                                                                                \
+    hipLaunchKernelGGL((k_chunk_colors_all<DEG, RAW>), dim3(grid_all), dim3(kGeomBlock), 0, s, f, cam.campos, g.means3D, g.shs,  \
+                       g.shs_rest, ws.records, ws.clamped)
+        if (g.raw) {
+            switch (f.D) {
+                case 0: GSR_CA(0, true); break;
+                case 1: GSR_CA(1, true); break;
+                case 2: GSR_CA(2, true); break;
+                default: GSR_CA(3, true); break;
+            }
+        } else {
+            switch (f.D) {
+                case 0: GSR_CA(0, false); break;
+                case 1: GSR_CA(1, false); break;
+                case 2: GSR_CA(2, false); break;
+                default: GSR_CA(3, false); break;
+            }
+        }
+#undef GSR_CA
+        GSR_LAUNCH_CHECK("chunk_colors_all", debug, s);
+        return GSR_OK;
+    }
     const int grid = (r1 - r0 + kGeomBlock - 1) / kGeomBlock;
 #define GSR_CC(DEG, RAW)                                                                                             \
     hipLaunchKernelGGL((k_chunk_colors<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, r0, r1, ws.order, cam.campos,     \
@@ -204,6 +313,8 @@ int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussi
 }
 
 // ---- K8 + K9: dL/d(screen-space quantities) -> dL/d(inputs) for Gaussians [g0, g1).
+__device__ __forceinline__ bool sh_wanted_or_read(const float *shs, int has_colpre) { return shs != nullptr && !has_colpre; }
+
 template <int DEG, bool RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g1, const float *__restrict__ view,
                                                          const float *__restrict__ proj, const float *__restrict__ campos,
@@ -245,15 +356,52 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
         live = (s0.x != 0.f) | (s0.y != 0.f) | (s0.z != 0.f) | (s0.w != 0.f) | (s1.x != 0.f) | (s1.y != 0.f) |
                (s1.z != 0.f) | (s1.w != 0.f) | (s2.x != 0.f);
     }
+    // The wave's SH rows ([M,3] per Gaussian, consecutive Gaussians contiguous in memory) come in through the same LDS
+    // staging rows the gradients leave by: 64 lanes x 16 B per load instruction instead of 64 single dwords 192 B apart (the
+    // per-lane strided form re-fetches every 64-B sector sixteen times).  geom_backward_one reads coefficient k and then
+    // overwrites it with its gradient, so one row serves both directions.
+    const int wave_first = i - lane;                           // first Gaussian of this wave
+    const int n_rows = min(64, g1 - wave_first);
+    const bool wave_live = __ballot(live) != 0ull;
+    if (sh_wanted_or_read(shs, has_colpre) && wave_live && rowf > 0 && n_rows > 0) {
+        float *stage_w = sh_stage + wv * (64 * 49);
+        if constexpr (RAW) {
+            for (int e = lane; e < n_rows * 3; e += 64) stage_w[(e / 3) * (rowf + 1) + e % 3] = shs[(size_t)wave_first * 3 + e];
+            const int row = rowf - 3;
+            if (row > 0) {
+                const float *src = shs_rest + (size_t)wave_first * row;
+                for (int e = lane; e < n_rows * row; e += 64) stage_w[(e / row) * (rowf + 1) + 3 + e % row] = src[e];
+            }
+        } else {
+            const float *src = shs + (size_t)wave_first * rowf;
+            const int total = n_rows * rowf;
+            if ((((uintptr_t)src) & 15) == 0) {
+                const float4 *src4 = reinterpret_cast<const float4 *>(src);
+                for (int e4 = lane; e4 < total / 4; e4 += 64) {
+                    const float4 v = src4[e4];
+                    const int e = 4 * e4;
+                    stage_w[(e / rowf) * (rowf + 1) + e % rowf] = v.x;
+                    stage_w[((e + 1) / rowf) * (rowf + 1) + (e + 1) % rowf] = v.y;
+                    stage_w[((e + 2) / rowf) * (rowf + 1) + (e + 2) % rowf] = v.z;
+                    stage_w[((e + 3) / rowf) * (rowf + 1) + (e + 3) % rowf] = v.w;
+                }
+                for (int e = (total / 4) * 4 + lane; e < total; e += 64) stage_w[(e / rowf) * (rowf + 1) + e % rowf] = src[e];
+            } else {
+                for (int e = lane; e < total; e += 64) stage_w[(e / rowf) * (rowf + 1) + e % rowf] = src[e];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     if (live) {
         float V[16], PV[16], cp[3];
 #pragma unroll
         for (int k = 0; k < 16; ++k) { V[k] = view[k]; PV[k] = proj[k]; }
         cp[0] = campos[0]; cp[1] = campos[1]; cp[2] = campos[2];
         GaussIn<DEG, RAW> in;
-        load_gaussian<DEG, RAW>(i, M, means, scales, rots, covpre, opac, shs, shs_rest, true, in);
+        load_gaussian<DEG, RAW>(i, M, means, scales, rots, covpre, opac, nullptr, nullptr, false, in);      // SH: from the LDS row
         const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
-        geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh(), has_colpre != 0,
+        geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, shs ? my_row : nullptr, has_colpre != 0,
                                clamped[i], sg, g, my_row, sh_wanted);
         if constexpr (RAW) activate_raw_backward(in.act, g);
     }
@@ -273,9 +421,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
     }
     }
     if (sh_wanted && rowf > 0) {
-        const int wave_first = i - lane;                           // first Gaussian of this wave
-        const int n_rows = min(64, g1 - wave_first);
-        const bool any_live = __ballot(live) != 0ull;
+        const bool any_live = wave_live;
         if (any_live) {
             const int nlive = live ? 3 * K : 0;
             for (int k = nlive; k < rowf; ++k) my_row[k] = 0.f;    // rows of dead lanes, coefficients above the active degree

@@ -140,8 +140,8 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
 int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
-int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, GeomWS &ws, bool debug,
-                        hipStream_t s);
+int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, int num_visible, GeomWS &ws,
+                        bool debug, hipStream_t s);
 int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, uint64_t emitted_before, GeomWS &gw, BinningWS &bw,
                          ImageWS &iw,
                          int *sort_result, bool debug, hipStream_t s);

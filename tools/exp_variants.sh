@@ -1,4 +1,4 @@
-for v in default fsingle f8; do
+for v in default; do
   if [ $v = default ]; then unset GSR_LIB_PATH; else export GSR_LIB_PATH=$PWD/structured-gaussian-splatting_amd/lib/var/libgsrast_$v.so; fi
   python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r2_x_$v.log 2> gpurun_out/r2_x_$v.err
 done
