@@ -209,26 +209,32 @@ __global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int 
         if ((threadIdx.x & 63) == 0) sh_end[c] = end;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    // chunk boundaries are a short integer recurrence over the searched ends: every one of the first GSR_MAX_CHUNKS threads
+    // replays it and then fetches its own chunk's instance bound, so the 2 x 8 dependent global loads happen side by side
+    const int c = threadIdx.x;
+    if (c >= GSR_MAX_CHUNKS) return;
     const uint32_t V = sh_V;
-    ctrl->V = V;
-    ctrl->open_count = 0;
-    ctrl->bnd[0] = 0;
-    ctrl->chunk_base[0] = 0;
-    for (int c = 0; c < GSR_MAX_CHUNKS; ++c) {
-        ctrl->chunk_full[c] = 0; ctrl->chunk_R[c] = 0; ctrl->bnd[c + 1] = V; ctrl->chunk_base[c + 1] = 0;
-    }
-    uint32_t begin = 0, nchunks = 0;
-    for (int c = 0; c < GSR_MAX_CHUNKS && begin < V; ++c) {
-        uint32_t end = sh_end[c];
+    uint32_t begin = 0, end = 0, nchunks = 0, my_begin = 0, my_end = 0;
+    bool mine = false;
+    for (int k = 0; k < GSR_MAX_CHUNKS && begin < V; ++k) {
+        end = sh_end[k];
         if (end <= begin) end = begin + 1;               // every chunk makes progress
         if (end > V) end = V;
-        ctrl->bnd[c + 1] = end;
-        ctrl->chunk_full[c] = offs_full[end - 1] - (begin ? offs_full[begin - 1] : 0u);
+        if (k == c) { my_begin = begin; my_end = end; mine = true; }
         begin = end;
-        nchunks = (uint32_t)c + 1;
+        nchunks = (uint32_t)k + 1;
     }
-    ctrl->num_chunks = nchunks;
+    ctrl->bnd[c + 1] = mine ? my_end : V;
+    ctrl->chunk_full[c] = mine ? offs_full[my_end - 1] - (my_begin ? offs_full[my_begin - 1] : 0u) : 0u;
+    ctrl->chunk_R[c] = 0;
+    ctrl->chunk_base[c + 1] = 0;
+    if (c == 0) {
+        ctrl->V = V;
+        ctrl->open_count = 0;
+        ctrl->bnd[0] = 0;
+        ctrl->chunk_base[0] = 0;
+        ctrl->num_chunks = nchunks;
+    }
 }
 
 int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
@@ -374,6 +380,8 @@ __global__ __launch_bounds__(W *kWave) void k_emit_team(FrameK f, int c, int r0,
     const TileRect t = unpack_rect(cc.z, cc.w);
     const int w = t.x1 - t.x0, total = w * (t.y1 - t.y0), ns = (total + kWave - 1) >> 6;
     const uint32_t mb = mask_base(offs_full, r0, r, (uint32_t)total);
+    float xe, ye;                                  // large splats: the quadrant mask from the alpha >= 1/255 bounding box (cheap;
+    splat_extent_q(ra.z, ra.w, rb.x, rb.y, xe, ye);    // their tiles are nearly all fully covered); small ones get the exact test
     uint32_t carry = 0;
     for (int s0 = 0; s0 < ns; s0 += T) {
         // exclusive scan of the popcounts of steps [s0, s0 + T)
@@ -405,8 +413,7 @@ __global__ __launch_bounds__(W *kWave) void k_emit_team(FrameK f, int c, int r0,
                 keys[slot] = (uint32_t)(ty * f.Gx + tx);
                 vals[slot] = slot;
                 // sub-tile culling for the blend kernels: which 8x8 quadrants of this tile the splat can reach
-                inst_gid[slot] = g | (quadrant_mask_q(ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, (float)(tx * GSR_TILE), (float)(ty * GSR_TILE))
-                                      << kQuadMaskShift);
+                inst_gid[slot] = g | (quadrant_mask_bbox(ra.x, ra.y, xe, ye, (float)(tx * GSR_TILE), (float)(ty * GSR_TILE)) << kQuadMaskShift);
             }
         }
         carry += wtot;

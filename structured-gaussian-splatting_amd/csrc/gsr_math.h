@@ -141,6 +141,33 @@ GSR_HD unsigned quadrant_mask_q(float sx, float sy, float qA, float qB, float qC
     return m;
 }
 
+// Cheaper, looser form of quadrant_mask_q for the emit kernels: the axis-aligned bounding box of the region where the
+// splat's alpha can reach 1/255 (half-widths xe, ye: two square roots per SPLAT, see splat_extent_q) against each
+// quadrant's pixel range: a handful of compares per tile.  Conservative (a superset of quadrant_mask_q's bits).
+GSR_HD void splat_extent_q(float qA, float qB, float qC, float lop, float &xe, float &ye)
+{
+    const float kLog2AlphaMin = -7.994353437f;
+    const float L = (lop - kLog2AlphaMin) * 1.001f + 0.02f;    // log2 units; covers rect_may_contribute_q's margins
+    const float det = 4.f * qA * qC - qB * qB;
+    if (!(qA < 0.f) || !(qC < 0.f) || !(det > 0.f) || !(L > 0.f)) { xe = L > 0.f ? 3.0e38f : -1.f; ye = xe; return; }
+    // p(d) - lop = qA dx^2 + qB dx dy + qC dy^2 >= -L  <=>  a dx^2 + 2 b dx dy + c dy^2 <= L with a = -qA, b = -qB/2, c = -qC;
+    // extents of that ellipse: |dx| <= sqrt(L c / (a c - b^2)), |dy| <= sqrt(L a / (a c - b^2)); a c - b^2 = det / 4
+    const float k = 4.f * L / det;
+    xe = sqrtf(k * -qC) * 1.001f + 0.01f;
+    ye = sqrtf(k * -qA) * 1.001f + 0.01f;
+}
+
+GSR_HD unsigned quadrant_mask_bbox(float sx, float sy, float xe, float ye, float px0, float py0)
+{
+    if (xe < 0.f) return 0u;
+    const float h = (float)(GSR_TILE / 2);
+    // quadrant columns [px0, px0 + 7] and [px0 + 8, px0 + 15] against [sx - xe, sx + xe]; rows likewise
+    const unsigned mx = ((sx - xe <= px0 + h - 1.f && sx + xe >= px0) ? 1u : 0u) | ((sx - xe <= px0 + 2.f * h - 1.f && sx + xe >= px0 + h) ? 2u : 0u);
+    const unsigned my = ((sy - ye <= py0 + h - 1.f && sy + ye >= py0) ? 1u : 0u) | ((sy - ye <= py0 + 2.f * h - 1.f && sy + ye >= py0 + h) ? 2u : 0u);
+    // bit k = qx + 2 qy
+    return ((my & 1u) ? mx : 0u) | ((my & 2u) ? (mx << 2) : 0u);
+}
+
 GSR_HD void slab_clip(TileRect &r, const FrameK &f)
 {
     if (r.y0 < f.ty0) r.y0 = f.ty0;

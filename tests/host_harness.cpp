@@ -81,6 +81,16 @@ extern "C" void hh_quadrant_mask(int n, const float *rec12, const int32_t *tx, c
     }
 }
 
+extern "C" void hh_quadrant_mask_bbox(int n, const float *rec12, const int32_t *tx, const int32_t *ty, uint8_t *out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float *r = rec12 + 12 * (size_t)i;
+        float xe, ye;
+        splat_extent_q(r[2], r[3], r[4], r[5], xe, ye);
+        out[i] = (uint8_t)quadrant_mask_bbox(r[0], r[1], xe, ye, (float)(tx[i] * GSR_TILE), (float)(ty[i] * GSR_TILE));
+    }
+}
+
 // a14: activations of the raw parameters and their chain rule (gsr_math.h activate_raw / activate_raw_backward).
 // in: log_scales[n,3], raw_q[n,4], logits[n]; upstream d_scale[n,3], d_q[n,4], d_op[n]
 // out: scale[n,3], q[n,4], op[n] and the gradients w.r.t. the raw values in g_ls[n,3], g_rq[n,4], g_logit[n]

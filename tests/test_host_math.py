@@ -198,6 +198,12 @@ def test_quadrant_culling_is_conservative(hh):
     n_set = sum(((mask >> k) & 1).sum() for k in range(4))
     reach = mask != 0
     assert 0.3 < n_set / (4.0 * reach.sum()) < 0.85, n_set / (4.0 * reach.sum())
+    # the cheap bounding-box form (k_emit_team) never clears a bit the exact form sets, and is not much looser
+    bbox = np.zeros(g.size, np.uint8)
+    hh.hh_quadrant_mask_bbox(g.size, _p(rec), _p(tx), _p(ty), _p(bbox))
+    assert ((mask & ~bbox) == 0).all()
+    n_bbox = sum(((bbox[reach] >> k) & 1).sum() for k in range(4))
+    assert n_bbox <= 1.3 * n_set, (n_bbox, n_set)
 
 
 def test_raw_activations_match_torch_autograd(hh):
