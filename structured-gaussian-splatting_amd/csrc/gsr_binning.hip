@@ -74,6 +74,7 @@ ImageWS carve_image(void *base, const FrameK &f)
     w.T_state = (float *)(b + o); o += align_up((N ? N : 1) * 4);
     w.last_enc = (int32_t *)(b + o); o += align_up((N ? N : 1) * 4);
     w.ranges = (uint2 *)(b + o); o += align_up((Tn ? Tn : 1) * 8 * GSR_MAX_CHUNKS);
+    w.tile_cnt = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);      // directly behind the ranges: one memset clears both
     w.open = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
     w.open_bits = (unsigned long long *)(b + o); o += align_up((size_t)(f.Gy > 0 ? f.Gy : 1) * (size_t)((f.Gx + 63) / 64 + 1) * 8);
     w.ctrl_scratch = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_open_count(FrameK f, int init, uint32_
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
 {
     const size_t Tn = (size_t)f.Gx * f.Gy;
-    GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, Tn * sizeof(uint2) * GSR_MAX_CHUNKS, s));
+    GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, (size_t)((char *)iw.tile_cnt - (char *)iw.ranges) + Tn * sizeof(uint32_t), s));
     ProfileScope prof("open_count", s);
     hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 1, iw.open, iw.open_bits, gw.ctrl);
     GSR_LAUNCH_CHECK("open_count(init)", debug, s);
@@ -306,13 +307,20 @@ __device__ __forceinline__ uint32_t mask_base(const uint32_t *__restrict__ offs_
     return (start >> 6) + (uint32_t)(r - r0);                  // disjoint ranges of ceil(total / 64) words per rank
 }
 
-template <int W>
+// GATHER: the chunk's tile lists are built by k_tile_gather (below) instead of emit + sort: the count pass then also
+// counts the instances per tile (atomics on consecutive counters: a wave step covers runs of consecutive tiles),
+// keeps the running popcount in front of every mask word (the instance's ordinal inside its Gaussian = its gradient
+// row) and one 32-byte metadata row per depth rank (rectangle, mask base, Gaussian, alpha bounding box).
+template <int W, bool GATHER>
 __global__ __launch_bounds__(W *kWave) void k_count_team(FrameK f, int c, int r0, const uint32_t *__restrict__ order,
                                                          const float4 *__restrict__ records,
                                                          const unsigned long long *__restrict__ open_bits,
                                                          const Ctrl *__restrict__ ctrl, const uint32_t *__restrict__ offs_full,
-                                                         unsigned long long *__restrict__ masks, uint32_t *__restrict__ cnt_open)
+                                                         unsigned long long *__restrict__ masks, uint32_t *__restrict__ cnt_open,
+                                                         uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ wprefix,
+                                                         uint4 *__restrict__ meta_a, float4 *__restrict__ meta_b)
 {
+    constexpr int T = W * kWave;
     __shared__ uint32_t sh_cnt[W];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = r0 + (int)blockIdx.x;
@@ -335,22 +343,52 @@ __global__ __launch_bounds__(W *kWave) void k_count_team(FrameK f, int c, int r0
         if (i < total) {
             const int tx = t.x0 + i % w, ty = t.y0 + i / w;
             want = ((open_bits[ty * W64 + (tx >> 6)] >> (tx & 63)) & 1ull) && tile_may_contribute(a.x, a.y, A, B, C, op, tx, ty);
+            if (GATHER && want) atomicAdd(&tile_cnt[ty * f.Gx + tx], 1u);
         }
         const unsigned long long m = __ballot(want);
         if (lane == 0) masks[mb + (uint32_t)s] = m;
         local += (uint32_t)__popcll(m);
     }
-    if (W == 1) {
-        if (lane == 0) cnt_open[r] = local;
-        return;
-    }
-    if (lane == 0) sh_cnt[wv] = local;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t sum = 0;
+    if (W > 1) {
+        if (lane == 0) sh_cnt[wv] = local;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t sum = 0;
 #pragma unroll
-        for (int i = 0; i < W; ++i) sum += sh_cnt[i];
-        cnt_open[r] = sum;
+            for (int i = 0; i < W; ++i) sum += sh_cnt[i];
+            cnt_open[r] = sum;
+        }
+    } else if (lane == 0) cnt_open[r] = local;
+    if constexpr (GATHER) {
+        if (threadIdx.x == 0) {
+            float xe, ye;
+            splat_extent_q(a.z, a.w, b.x, b.y, xe, ye);
+            meta_a[r - r0] = make_uint4((uint32_t)t.x0 | ((uint32_t)t.y0 << 16), (uint32_t)w | ((uint32_t)(t.y1 - t.y0) << 16), mb, g);
+            meta_b[r - r0] = make_float4(a.x, a.y, xe, ye);
+        }
+        __syncthreads();                                       // the block's mask words are visible to all its threads
+        uint32_t carry = 0;
+        for (int s0 = 0; s0 < ns; s0 += T) {                   // exclusive scan of the popcounts of steps [s0, s0 + T)
+            const int s = s0 + (int)threadIdx.x;
+            const uint32_t pc = s < ns ? (uint32_t)__popcll(masks[mb + (uint32_t)s]) : 0u;
+            uint32_t inc = pc;
+#pragma unroll
+            for (int off = 1; off < kWave; off <<= 1) {
+                const uint32_t v = __shfl_up(inc, off);
+                if (lane >= off) inc += v;
+            }
+            uint32_t wbase = 0, wtot = inc;
+            if (W > 1) {
+                __syncthreads();
+                if (lane == 63) sh_cnt[wv] = inc;
+                __syncthreads();
+                wtot = 0;
+#pragma unroll
+                for (int i = 0; i < W; ++i) { const uint32_t v = sh_cnt[i]; if (i < wv) wbase += v; wtot += v; }
+            } else wtot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            if (s < ns) wprefix[mb + (uint32_t)s] = carry + wbase + inc - pc;
+            carry += wtot;
+        }
     }
 }
 
@@ -570,6 +608,151 @@ __global__ __launch_bounds__(kBinBlock) void k_bin_chunk(FrameK f, int c, int r0
     }
 }
 
+// ---- variant A': the tile lists of a chunk of few, large splats by GATHER, not by sort.  The count pass left the
+// per-tile instance counts; k_tile_ranges turns them into the tiles' ranges (exclusive scan in tile order: exactly
+// where the stable sort by tile id would put them) and k_tile_gather lets one wave per open tile walk the chunk's
+// depth ranks, 64 x kGatherUnroll per step, test "is this tile inside the rank's rectangle, and did the count pass
+// accept it" (one bit of the rank's mask words) and append the accepted ranks to the tile's list in rank order =
+// depth order.  The result is bit for bit what emit + stable sort + ranges produce; the work is ranks x open tiles
+// bit tests (44 M for cfg3's first chunk) instead of a 2 M-key radix sort.
+__global__ __launch_bounds__(1024) void k_tile_ranges(FrameK f, int c, const Ctrl *__restrict__ ctrl, uint32_t *__restrict__ tile_cnt,
+                                                      uint2 *__restrict__ ranges_c)
+{
+    __shared__ uint32_t sh_wave[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int t_begin = f.ty0 * f.Gx, t_end = f.ty1 * f.Gx;
+    uint32_t carry = ctrl->chunk_base[c];
+    for (int t0 = t_begin; t0 < t_end; t0 += 1024) {
+        const int t = t0 + (int)threadIdx.x;
+        const uint32_t v = t < t_end ? tile_cnt[t] : 0u;
+        if (v) tile_cnt[t] = 0u;                               // ready for the next chunk / frame
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t u = __shfl_up(inc, off);
+            if (lane >= off) inc += u;
+        }
+        __syncthreads();
+        if (lane == 63) sh_wave[wv] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, wtot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const uint32_t u = sh_wave[i]; if (i < wv) wbase += u; wtot += u; }
+        if (v) { const uint32_t b = carry + wbase + inc - v; ranges_c[t] = make_uint2(b, b + v); }
+        carry += wtot;
+    }
+}
+
+constexpr int kGatherBlock = 512;            // 8 tiles per block share the ranks' metadata through LDS
+
+// the heavy half of k_tile_gather: `cnt` (<= 64) queued (rank, tile-in-rectangle) candidates of one tile, one per lane
+__device__ __forceinline__ uint32_t gather_flush(const uint2 *q, int cnt, int lane, unsigned long long below, uint32_t out,
+                                                 uint32_t base, int r0, int tx, int ty, const uint4 *__restrict__ meta_a,
+                                                 const float4 *__restrict__ meta_b, const unsigned long long *__restrict__ masks,
+                                                 const uint32_t *__restrict__ wprefix, const uint32_t *__restrict__ cnt_open,
+                                                 const uint32_t *__restrict__ offs_open, uint32_t *__restrict__ sorted_gid,
+                                                 uint32_t *__restrict__ sorted_slot)
+{
+    bool acc = false;
+    unsigned long long word = 0ull;
+    uint32_t pre = 0, first = 0, g = 0, bit = 0;
+    float4 mb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < cnt) {                                          // one round of loads, all independent
+        const uint2 e = q[lane];
+        const uint32_t r = e.y >> 6;
+        bit = e.y & 63u;
+        word = masks[e.x];
+        pre = wprefix[e.x];
+        g = meta_a[r].w;
+        mb = meta_b[r];
+        first = offs_open[r0 + r] - cnt_open[r0 + r];
+        acc = (word >> bit) & 1ull;
+    }
+    const unsigned long long m = __ballot(acc);
+    if (acc) {
+        const uint32_t k = out + (uint32_t)__popcll(m & below);
+        const uint32_t ordinal = pre + (uint32_t)__popcll(word & ((1ull << bit) - 1ull));
+        sorted_gid[k] = g | (quadrant_mask_bbox(mb.x, mb.y, mb.z, mb.w, (float)(tx * GSR_TILE), (float)(ty * GSR_TILE)) << kQuadMaskShift);
+        sorted_slot[k] = base + first + ordinal;
+    }
+    return out + (uint32_t)__popcll(m);
+}
+
+__global__ __launch_bounds__(kGatherBlock) void k_tile_gather(FrameK f, int c, int r0, int n, const Ctrl *__restrict__ ctrl,
+                                                              const uint2 *__restrict__ ranges_c, const uint4 *__restrict__ meta_a,
+                                                              const float4 *__restrict__ meta_b,
+                                                              const unsigned long long *__restrict__ masks,
+                                                              const uint32_t *__restrict__ wprefix, const uint32_t *__restrict__ cnt_open,
+                                                              const uint32_t *__restrict__ offs_open, uint32_t *__restrict__ sorted_gid,
+                                                              uint32_t *__restrict__ sorted_slot, uint32_t *__restrict__ row_begin)
+{
+    __shared__ uint4 sh_meta[kGatherBlock];
+    __shared__ uint2 sh_q[kGatherBlock / kWave][2 * kWave];    // per tile: ranks whose rectangle holds it, waiting for a full wave
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t base = ctrl->chunk_base[c];
+    const bool nothing = ctrl->chunk_R[c] == 0u;
+    {                                                          // the ranks' first gradient rows
+        const int r = (int)blockIdx.x * kGatherBlock + (int)threadIdx.x;
+        if (r < n) {
+            const uint32_t cnt = nothing ? 0u : cnt_open[r0 + r];
+            row_begin[r0 + r] = base + (nothing ? 0u : offs_open[r0 + r] - cnt);
+        }
+    }
+    if (nothing) return;
+    const int slab_tiles = (f.ty1 - f.ty0) * f.Gx;
+    const int t_local = (int)blockIdx.x * (kGatherBlock / kWave) + wv;
+    if ((int)blockIdx.x * (kGatherBlock / kWave) >= slab_tiles) return;       // block-uniform
+    const int tile = f.ty0 * f.Gx + t_local;
+    uint2 rng = make_uint2(0u, 0u);
+    if (t_local < slab_tiles) rng = ranges_c[tile];
+    const int ty = tile / f.Gx, tx = tile - ty * f.Gx;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint2 *q = sh_q[wv];
+    uint32_t out = rng.x;
+    int qn = 0;                                                // wave-uniform
+    uint4 next = (int)threadIdx.x < n ? meta_a[threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
+    for (int k0 = 0; k0 < n; k0 += kGatherBlock) {
+        __syncthreads();
+        sh_meta[threadIdx.x] = next;
+        __syncthreads();
+        {
+            const int r = k0 + kGatherBlock + (int)threadIdx.x;
+            next = r < n ? meta_a[r] : make_uint4(0u, 0u, 0u, 0u);           // w = h = 0: never inside
+        }
+        if (out >= rng.y) continue;                            // this tile's list is complete (or empty); keep the barriers
+#pragma unroll 2
+        for (int u = 0; u < kGatherBlock / kWave; ++u) {
+            if (k0 + u * kWave >= n) break;
+            const uint4 ma = sh_meta[u * kWave + lane];
+            const uint32_t dx = (uint32_t)tx - (ma.x & 0xFFFFu), dy = (uint32_t)ty - (ma.x >> 16), w = ma.y & 0xFFFFu;
+            const bool in = dx < w && dy < (ma.y >> 16);
+            const unsigned long long m_in = __ballot(in);
+            if (m_in == 0ull) continue;
+            if (in) {
+                const uint32_t idx = dy * w + dx;
+                q[qn + __popcll(m_in & below)] = make_uint2(ma.z + (idx >> 6), ((uint32_t)(k0 + u * kWave + lane) << 6) | (idx & 63u));
+            }
+            qn += __popcll(m_in);
+            if (qn >= kWave) {
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                out = gather_flush(q, kWave, lane, below, out, base, r0, tx, ty, meta_a, meta_b, masks, wprefix, cnt_open, offs_open,
+                                   sorted_gid, sorted_slot);
+                const uint2 e = q[kWave + lane];
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                q[lane] = e;
+                qn -= kWave;
+            }
+        }
+    }
+    if (qn > 0 && out < rng.y) {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        gather_flush(q, qn, lane, below, out, base, r0, tx, ty, meta_a, meta_b, masks, wprefix, cnt_open, offs_open, sorted_gid, sorted_slot);
+    }
+}
+
 // ---- ranges of the chunk's sorted list (grid-stride, element count on the device)
 __global__ __launch_bounds__(kBinBlock) void k_ranges(int c, const Ctrl *__restrict__ ctrl, const uint32_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ slots, const uint32_t *__restrict__ inst_gid,
@@ -614,23 +797,52 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     // emitted count; ceil(n_max / 64) + n words of 8 bytes fit in the n_max slots the caller has checked are there: a team
     // chunk averages >= 24 tiles per Gaussian)
     unsigned long long *masks = reinterpret_cast<unsigned long long *>(bw.keys[1] + ((emitted_before + 1) & ~(uint64_t)1));
+    // A' (gather instead of emit + sort) when the ranks x tiles bit tests are cheaper than sorting the instances; its
+    // scratch (mask prefixes, rank metadata: n_max / 64 + 9 n + 4 words) sits in the other idle key buffer
+    const uint64_t slab_tiles = (uint64_t)(f.ty1 - f.ty0) * (uint64_t)f.Gx;
+    const uint64_t scratch_words = n_max / 64 + 1 + 9 * (uint64_t)n + 4;
+    const bool gather = !flat && !getenv("GSR_NO_GATHER") && n < (1 << 26) && (uint64_t)n * slab_tiles <= 24 * n_max + (1ull << 22) &&
+                        scratch_words <= n_max;
+    uint32_t *scratch = bw.keys[0] + ((emitted_before + 3) & ~(uint64_t)3);
+    uint4 *meta_a = reinterpret_cast<uint4 *>(scratch);
+    float4 *meta_b = reinterpret_cast<float4 *>(scratch + 4 * (size_t)n);
+    uint32_t *wprefix = scratch + 8 * (size_t)n;
+    const int tile_bits = msb_plus1((uint32_t)(Tn ? Tn - 1 : 0));
     {
         ProfileScope prof("count_open", s);
-#define GSR_CT(W)                                                                                                          \
-    hipLaunchKernelGGL(k_count_team<W>, dim3(n), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, iw.open_bits, gw.ctrl, \
-                       gw.offs_full, masks, gw.cnt_open)
+#define GSR_CT(W, G)                                                                                                       \
+    hipLaunchKernelGGL((k_count_team<W, G>), dim3(n), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, iw.open_bits, gw.ctrl, \
+                       gw.offs_full, masks, gw.cnt_open, iw.tile_cnt, wprefix, meta_a, meta_b)
         if (flat)
             hipLaunchKernelGGL(k_bin_chunk<false>, dim3(bin_blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records,
                                iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);
-        else if (team == 16) GSR_CT(16);
-        else if (team == 4) GSR_CT(4);
-        else GSR_CT(1);
+        else if (team == 16) { if (gather) GSR_CT(16, true); else GSR_CT(16, false); }
+        else if (team == 4) { if (gather) GSR_CT(4, true); else GSR_CT(4, false); }
+        else { if (gather) GSR_CT(1, true); else GSR_CT(1, false); }
 #undef GSR_CT
         GSR_LAUNCH_CHECK("count_open", debug, s);
     }
     if ((rc = launch_scan_inclusive(gw.cnt_open + r0, gw.offs_open + r0, n, gw.scan_temp, &gw.ctrl->chunk_R[c],
                                     &gw.ctrl->chunk_base[c], &gw.ctrl->chunk_base[c + 1], "scan_open", debug, s)))
         return rc;
+    if (gather) {
+        // the list ends where the radix passes would have left it, so that all chunks of a frame agree on the buffer
+        const int res = (((tile_bits > 0 ? tile_bits : 1) + 7) / 8) & 1;
+        *sort_result = res;
+        {
+            ProfileScope prof("tile_ranges", s);
+            hipLaunchKernelGGL(k_tile_ranges, dim3(1), dim3(1024), 0, s, f, c, gw.ctrl, iw.tile_cnt, iw.ranges + (size_t)c * Tn);
+            GSR_LAUNCH_CHECK("tile_ranges", debug, s);
+        }
+        ProfileScope prof("tile_gather", s);
+        const uint64_t tile_blocks = (slab_tiles + kGatherBlock / kWave - 1) / (kGatherBlock / kWave);
+        const uint64_t rank_blocks = ((uint64_t)n + kGatherBlock - 1) / kGatherBlock;
+        const uint64_t blocks = tile_blocks > rank_blocks ? tile_blocks : rank_blocks;
+        hipLaunchKernelGGL(k_tile_gather, dim3((unsigned)blocks), dim3(kGatherBlock), 0, s, f, c, r0, n, gw.ctrl, iw.ranges + (size_t)c * Tn,
+                           meta_a, meta_b, masks, wprefix, gw.cnt_open, gw.offs_open, bw.sorted_gid, bw.vals[res], gw.row_begin);
+        GSR_LAUNCH_CHECK("tile_gather", debug, s);
+        return GSR_OK;
+    }
     {
         ProfileScope prof("emit", s);
 #define GSR_ET(W)                                                                                                          \
@@ -645,7 +857,6 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
 #undef GSR_ET
         GSR_LAUNCH_CHECK("emit", debug, s);
     }
-    const int tile_bits = msb_plus1((uint32_t)(Tn ? Tn - 1 : 0));
     if ((rc = launch_radix_sort<uint32_t>(bw.keys, bw.vals, &gw.ctrl->chunk_R[c], 0, n_max, &gw.ctrl->chunk_base[c], 0,
                                           tile_bits > 0 ? tile_bits : 1, gw.radix_temp, sort_result, "tile_sort", debug, s)))
         return rc;

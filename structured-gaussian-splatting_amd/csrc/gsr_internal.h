@@ -98,6 +98,7 @@ struct ImageWS {                // O(N + Tn): the reference's imgBuffer
     float *T_state;             // [N]  running / final transmittance; negative = pixel hit the cut-off
     int32_t *last_enc;          // [N]  (chunk + 1) << 26 | contributor position in that chunk's range
     uint2 *ranges;              // [GSR_MAX_CHUNKS][Tn]
+    uint32_t *tile_cnt;         // [Tn] instances per tile of the chunk being binned (gather variant; zero between chunks)
     uint32_t *open;             // [Tn] 1 = tile still has an unsaturated pixel (0 outside the slab)
     unsigned long long *open_bits;   // [Gy][ceil(Gx/64)] the same flags, one bit per tile (rebuilt at chunk boundaries)
     Ctrl *ctrl_scratch;         // stand-in control block for frames without a geometry workspace (P == 0)
