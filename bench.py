@@ -20,6 +20,7 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys:
   reference_loss_composition   the step with the reference's own two-call loss (l1_loss + ssim: utils/loss_utils.py)
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -55,6 +56,12 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
         "emit": 12 * Re + 56 * Vb,                          # K3: key 4 + slot 4 + Gaussian 4 per instance
         "tile_sort": 16 * Re,                               # K4 minimum: one read + one write of (tile, slot)
         "ranges": 16 * Re + 8 * Tn,                         # K5 (+ sorted position -> Gaussian)
+        # gather variant of K3-K5 (chunks of few large splats): counts in, ranges out; then per instance the accept bit's
+        # mask word 8 + prefix 4 in, (Gaussian, slot) 8 out, per rank 32 B of metadata
+        "tile_ranges": 12 * Tn, "tile_gather": 20 * Re + 32 * Vb,
+        # a14: exp / normalize / sigmoid of (3 + 4 + 1) floats per Gaussian: 32 in + 32 out; backward reads the 8 incoming
+        # gradients, the saved outputs / raw quaternion (8) and writes 8
+        "activations_fwd": 64 * P, "activations_bwd": 96 * P,
         "render_fwd": 40 * Re + 20 * N,                     # K6: id 4 + record 36 per instance; 20 B/px
         "render_bwd": 76 * Re + 20 * N,                     # K7: 40 read + 36 written per instance; 20 B/px
         "reduce_rows": 36 * Re + 36 * Vb,                   # deterministic reduction (replaces atomic RMW)
@@ -130,7 +137,7 @@ def main():
         "raster_ms_per_step": m["raster_ms_per_step"], "profiled_ms_per_step": m["profiled_ms_per_step"],
         "kernels": m["kernels"], "roofline": m["roofline"], "cpu_baseline": None,
     }
-    for k in ("fused_activations", "getter_fusion", "reference_loss_composition"):
+    for k in ("torch_getters", "fused_activations", "getter_fusion", "reference_loss_composition"):
         if m.get(k) is not None:
             line[k] = m[k]
     if single and not args.no_secondary and args.workload == "cfg3":
@@ -166,8 +173,16 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
     cfg = S.CONFIGS[workload]
     scene, cam = S.make_config(workload)
     scene, cam = scene.to(dev), cam.to(dev)
-    model = GaussianParams(scene).to(dev)
-    params = [p for p in model.parameters()]
+    # The parameter store is this package's scene.GaussianModel: the reference class's public surface (getters, optimizer
+    # groups, densification) with the getters as native ops.  `store` is the plain torch-getter
+    # store (the reference's own four torch getters, what a caller who keeps the reference's GaussianModel class runs);
+    # it is timed beside `value` as "torch_getters".
+    from scene import GaussianModel
+    model = GaussianModel(scene.sh_degree)
+    model.adopt_scene(scene, device=dev)
+    store = GaussianParams(scene).to(dev)
+    active = {"m": model}
+    params = list(model._t.values()) + [p for p in store.parameters()]
     bg = torch.zeros(3, device=dev)
     gt = torch.rand(3, cfg["H"], cfg["W"], generator=torch.Generator().manual_seed(cfg["seed"] + 100)).to(dev)
     pipe = Pipe()
@@ -180,7 +195,7 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
     def step():
         for p in params:
             p.grad = None
-        out = render(cam, model, pipe, bg) if sharded is None else sharded.render(cam, model, pipe, bg)
+        out = render(cam, active["m"], pipe, bg) if sharded is None else sharded.render(cam, active["m"], pipe, bg)
         # same loss; on N > 1 every rank evaluates the terms of its own rows (slab-local, one 8-byte all-reduce)
         if loss_fn["f"] is not None:
             loss = loss_fn["f"](out["render"], gt)
@@ -196,13 +211,19 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
             torch.cuda.synchronize(dev)
 
     def timed(n, w):
-        for _ in range(w):
+        gc.collect()                 # a generation-2 collection landing inside a 30 ms window is a 40 ms outlier (measured);
+        for _ in range(w):           # collect before the warm-up, so that the device is busy again when the clock starts
             step()
         sync()
         t0 = time.perf_counter()
+        per_step = []
         for _ in range(n):
             o = step()
+            if os.environ.get("GSR_BENCH_TRACE"):
+                torch.cuda.synchronize(dev); per_step.append(round(1e3 * (time.perf_counter() - t0), 2))
         sync()
+        if per_step:
+            print("trace", per_step, file=sys.stderr)
         return time.perf_counter() - t0, o
 
     # (1) the timed region: EXACTLY K steps, no instrumentation inside
@@ -217,6 +238,14 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
         N.profile_enable(False)
     res = {}
     if extras:
+        # (2b) the same step with the reference's torch getters (exp / normalize / sigmoid / cat and their autograd backward)
+        active["m"] = store
+        el, _ = timed(steps, max(warmup, 1))
+        res["torch_getters"] = {
+            "value": round(steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / steps, 4),
+            "what": "same step with a parameter store whose getters are the reference's torch ops (gaussian_params.GaussianParams "
+                    "= scene/gaussian_model.py:101-125 verbatim): what a caller who keeps the reference's own GaussianModel class "
+                    "gets from the drop-in rasterizer alone"}
         # (3) extension, reported beside `value`, never as it: the activations of the parameter store
         # fused into the HIP kernels (pipe.fused_activations -> GaussianRasterizer.forward_raw)
         pipe.fused_activations = True
@@ -231,6 +260,7 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
         _dgr.FUSE_GETTERS = True
         el, _ = timed(steps, max(warmup, 1))
         _dgr.FUSE_GETTERS = False
+        active["m"] = model
         res["getter_fusion"] = {
             "value": round(steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / steps, 4),
             "what": "unchanged caller (reference-style render(): getters + GaussianRasterizer.forward) with "

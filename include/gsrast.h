@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 8
+#define GSR_VERSION 9
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -235,6 +235,25 @@ int gsr_dist2_knn3(int32_t P, const float *xyz, float *mean_dist2, void *workspa
  * scene/gaussian_model.py:173) over n contiguous fp32 elements in a single pass.  step = 1 for the first update. */
 int gsr_adam_step(int64_t n, float *param, const float *grad, float *exp_avg, float *exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, int64_t step, void *stream);
+/* The same step over `rows` rows of `row_len` >= 4 contiguous elements whose first `split` elements use
+ * lr_head and the rest lr_tail: the interleaved SH table [P, M, 3] (row_len = 3 M, split = 3), which stands for the
+ * reference's two tensors _features_dc (lr = feature_lr) and _features_rest (lr = feature_lr / 20,
+ * scene/gaussian_model.py:166-168).  Element for element the result equals two gsr_adam_step calls on the two tensors. */
+int gsr_adam_step_split(int64_t rows, int32_t row_len, int32_t split, float *param, const float *grad, float *exp_avg,
+                        float *exp_avg_sq, float lr_head, float lr_tail, float beta1, float beta2, float eps, int64_t step,
+                        void *stream);
+
+/* ---- the activations between the optimizer's raw parameters and the rasterizer's inputs, the
+ * getters of scene/gaussian_model.py:101-125 (setup_functions :47-60):
+ *   scales [P,3] = exp(scaling_raw)   rotations [P,4] = rotation_raw / max(|rotation_raw|_2, 1e-12)   opacities [P] = sigmoid(opacity_raw)
+ * in one launch; a NULL input skips that tensor (its output must be NULL too).  Pointers 16-byte aligned. */
+int gsr_activations_forward(int64_t P, const float *scaling_raw, const float *rotation_raw, const float *opacity_raw, float *scales,
+                            float *rotations, float *opacities, void *stream);
+/* Their backward in one launch: scales / opacities are the FORWARD OUTPUTS, rotation_raw the forward input.  A NULL
+ * dL_d*_raw output skips that tensor. */
+int gsr_activations_backward(int64_t P, const float *scales, const float *rotation_raw, const float *opacities,
+                             const float *dL_dscales, const float *dL_drotations, const float *dL_dopacities,
+                             float *dL_dscaling_raw, float *dL_drotation_raw, float *dL_dopacity_raw, void *stream);
 
 /* ---- the densification bookkeeping of one training iteration (train.py:127-130,
  * scene/gaussian_model.py:415-417) in one pass without a host synchronisation: for every Gaussian with

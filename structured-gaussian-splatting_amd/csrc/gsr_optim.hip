@@ -9,19 +9,30 @@ namespace gsr {
 
 constexpr int kAdamBlock = 256;
 
+// SPLIT: rows of `row_len` elements (>= 4) whose first `split` elements step with `step_size` and the rest
+// with `step_tail`: the interleaved SH table [P, 16, 3] of this package's GaussianModel, where the reference keeps
+// f_dc (lr = feature_lr) and f_rest (lr = feature_lr / 20) as two tensors (scene/gaussian_model.py:166-168).
+template <bool SPLIT>
 __global__ __launch_bounds__(kAdamBlock) void k_adam(size_t n, float *__restrict__ p, const float *__restrict__ g,
                                                      float *__restrict__ m, float *__restrict__ v, float one_minus_b1,
-                                                     float b2, float one_minus_b2, float step_size, float inv_bc2_sqrt, float eps)
+                                                     float b2, float one_minus_b2, float step_size, float inv_bc2_sqrt, float eps,
+                                                     uint32_t row_len, uint32_t split, float step_tail)
 {
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * kAdamBlock;
     for (size_t i = (size_t)blockIdx.x * kAdamBlock + threadIdx.x; i < n4; i += stride) {
         float4 pp = reinterpret_cast<float4 *>(p)[i], mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
         const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+        float4 st = make_float4(step_size, step_size, step_size, step_size);
+        if (SPLIT) {
+            const uint32_t col = (uint32_t)((i * 4) % row_len);
+            auto pick = [&](uint32_t c) { c = c >= row_len ? c - row_len : c; return c < split ? step_size : step_tail; };
+            st = make_float4(pick(col), pick(col + 1), pick(col + 2), pick(col + 3));
+        }
 #define GSR_ADAM1(c)                                                          \
         mm.c = mm.c + (gg.c - mm.c) * one_minus_b1;                           \
         vv.c = vv.c * b2 + one_minus_b2 * gg.c * gg.c;                        \
-        pp.c = pp.c - step_size * (mm.c / (sqrtf(vv.c) * inv_bc2_sqrt + eps));
+        pp.c = pp.c - st.c * (mm.c / (sqrtf(vv.c) * inv_bc2_sqrt + eps));
         GSR_ADAM1(x) GSR_ADAM1(y) GSR_ADAM1(z) GSR_ADAM1(w)
         reinterpret_cast<float4 *>(p)[i] = pp; reinterpret_cast<float4 *>(m)[i] = mm; reinterpret_cast<float4 *>(v)[i] = vv;
     }
@@ -30,7 +41,8 @@ __global__ __launch_bounds__(kAdamBlock) void k_adam(size_t n, float *__restrict
         const float gg = g[i];
         mm = mm + (gg - mm) * one_minus_b1;
         vv = vv * b2 + one_minus_b2 * gg * gg;
-        p[i] = p[i] - step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+        const float st = SPLIT && (uint32_t)(i % row_len) >= split ? step_tail : step_size;
+        p[i] = p[i] - st * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
         m[i] = mm; v[i] = vv;
     }
 #undef GSR_ADAM1
@@ -89,8 +101,31 @@ extern "C" int gsr_adam_step(int64_t n, float *param, const float *grad, float *
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     ProfileScope prof("adam", s);
-    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(kAdamBlock), 0, s, (size_t)n, param, grad, exp_avg, exp_avg_sq, 1.f - beta1,
-                       beta2, 1.f - beta2, step_size, inv_bc2_sqrt, eps);
+    hipLaunchKernelGGL(k_adam<false>, dim3((unsigned)blocks), dim3(kAdamBlock), 0, s, (size_t)n, param, grad, exp_avg, exp_avg_sq, 1.f - beta1,
+                       beta2, 1.f - beta2, step_size, inv_bc2_sqrt, eps, 0u, 0u, 0.f);
+    GSR_LAUNCH_CHECK("adam", false, s);
+    return GSR_OK;
+}
+
+extern "C" int gsr_adam_step_split(int64_t rows, int32_t row_len, int32_t split, float *param, const float *grad, float *exp_avg,
+                                   float *exp_avg_sq, float lr_head, float lr_tail, float beta1, float beta2, float eps, int64_t step,
+                                   void *stream)
+{
+    if (rows < 0 || step < 1 || row_len < 4 || split < 0 || split > row_len ||
+        (rows > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) {
+        set_error("gsr_adam_step_split: bad argument (row_len >= 4, 0 <= split <= row_len)");
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    if (rows == 0) return GSR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)rows * (size_t)row_len;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_head = (float)((double)lr_head / bc1), step_tail = (float)((double)lr_tail / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    size_t blocks = (n / 4 + kAdamBlock - 1) / kAdamBlock;
+    if (blocks > 4096) blocks = 4096;
+    ProfileScope prof("adam", s);
+    hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)blocks), dim3(kAdamBlock), 0, s, n, param, grad, exp_avg, exp_avg_sq, 1.f - beta1, beta2,
+                       1.f - beta2, step_head, inv_bc2_sqrt, eps, (uint32_t)row_len, (uint32_t)split, step_tail);
     GSR_LAUNCH_CHECK("adam", false, s);
     return GSR_OK;
 }

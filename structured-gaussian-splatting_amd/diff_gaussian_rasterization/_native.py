@@ -63,7 +63,8 @@ class DebugViews(C.Structure):
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess",
            "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows", "gsr_loss_l1_backward",
-           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_densify_stats")
+           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_adam_step_split", "gsr_densify_stats",
+           "gsr_activations_forward", "gsr_activations_backward")
 
 _lib = None
 
@@ -306,6 +307,38 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
     _check(load().gsr_adam_step(C.c_int64(param.numel()), _ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), C.c_float(lr),
                                 C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_int64(int(step)),
                                 _stream(param.device)), "gsr_adam_step")
+
+
+def adam_step_split(param, grad, exp_avg, exp_avg_sq, split, lr_head, lr_tail, beta1, beta2, eps, step):
+    """param [rows, ...] contiguous; the first `split` elements of every row step with lr_head, the rest with lr_tail."""
+    rows = param.shape[0]
+    row_len = param.numel() // max(rows, 1)
+    _check(load().gsr_adam_step_split(C.c_int64(rows), C.c_int32(row_len), C.c_int32(int(split)), _ptr(param), _ptr(grad), _ptr(exp_avg),
+                                      _ptr(exp_avg_sq), C.c_float(lr_head), C.c_float(lr_tail), C.c_float(beta1), C.c_float(beta2),
+                                      C.c_float(eps), C.c_int64(int(step)), _stream(param.device)), "gsr_adam_step_split")
+
+
+def activations_forward(scaling_raw, rotation_raw, opacity_raw):
+    """(exp, normalize, sigmoid) of the three raw tensors in one launch; any may be None."""
+    some = next(t for t in (scaling_raw, rotation_raw, opacity_raw) if t is not None)
+    P = some.shape[0]
+    outs = [None if t is None else torch.empty_like(t) for t in (scaling_raw, rotation_raw, opacity_raw)]
+    with torch.cuda.device(some.device):
+        _check(load().gsr_activations_forward(C.c_int64(P), _ptr(scaling_raw), _ptr(rotation_raw), _ptr(opacity_raw), _ptr(outs[0]),
+                                              _ptr(outs[1]), _ptr(outs[2]), _stream(some.device)), "gsr_activations_forward")
+    return tuple(outs)
+
+
+def activations_backward(scales, rotation_raw, opacities, g_scales, g_rotations, g_opacities):
+    """Gradients w.r.t. the raw tensors; a None incoming gradient gives a None result."""
+    some = next(t for t in (scales, rotation_raw, opacities) if t is not None)
+    P = some.shape[0]
+    outs = [None if g is None else torch.empty_like(g) for g in (g_scales, g_rotations, g_opacities)]
+    with torch.cuda.device(some.device):
+        _check(load().gsr_activations_backward(C.c_int64(P), _ptr(scales), _ptr(rotation_raw), _ptr(opacities), _ptr(g_scales),
+                                               _ptr(g_rotations), _ptr(g_opacities), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                               _stream(some.device)), "gsr_activations_backward")
+    return tuple(outs)
 
 
 def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom):

@@ -64,7 +64,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # plain path, where a frozen parameter receives no gradient
     frozen = any(getattr(pc, f, False) for f in ("freeze_means", "freeze_scales", "freeze_rotations", "freeze_opacities"))
     if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.compute_cov3D_python
-            and not pipe.convert_SHs_python and hasattr(pc, "_features_rest") and not frozen):
+            and not pipe.convert_SHs_python and hasattr(pc, "_features_rest") and not frozen
+            and not getattr(pc, "packed_features", False)):      # scene.GaussianModel: its getters are already native
         rendered_image, radii = rasterizer.forward_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest,
                                                        pc._opacity, pc._scaling, pc._rotation)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,

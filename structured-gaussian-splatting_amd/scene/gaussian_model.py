@@ -4,10 +4,21 @@ of the rasterizer's inputs and the consumer of its `means2D.grad` / `radii` outp
 Same public surface and semantics as the reference class (getters :101-128, create_from_pcd :134-157,
 training_setup :159-177, update_learning_rate :179-185, PLY IO :201-266, reset_opacity :220-223,
 densify_and_prune :399-413, add_densification_stats :415-417, capture/restore :67-99), organised differently:
-the six per-Gaussian tensors live in ONE table keyed by the optimizer group name, and every structural edit
-(prune, clone, split, opacity reset) goes through a single `_rebuild` that rewrites parameters and Adam moments
-together.  Runs on whatever device the tensors live on; the native pieces it calls (rasterizer, distCUDA2)
-are HIP-only.
+the per-Gaussian tensors live in ONE table, and every structural edit (prune, clone, split, opacity reset) goes
+through a single `_rebuild` that rewrites parameters and Adam moments together.
+
+Two things are laid out for the rasterizer rather than as the reference has them (the producer
+side of the hot path; 0.45 ms of a 1.4 ms training step at 1e6 Gaussians when done as torch ops):
+  * `_features_dc` [P,1,3] and `_features_rest` [P,M-1,3] are the two column ranges of ONE leaf tensor `_features`
+    [P,M,3], so `get_features` (the reference's torch.cat, 384 MB of traffic per call at P = 1e6, and as much again
+    in its backward) is that tensor itself: no copy forward, and the rasterizer's dL/dshs IS its gradient.  The
+    optimizer keeps the reference's six named groups; "f_dc" holds `_features` and steps its first column with its
+    own lr and the others with the lr of the (parameter-less) group "f_rest" — element for element what Adam on the
+    two separate tensors does (fused_adam.py, gsr_adam_step_split).
+  * `get_scaling`, `get_rotation`, `get_opacity` share one native evaluation (scene/activations.py: one HIP launch
+    forward, one backward, for all three) instead of ~20 torch kernels.
+Runs on whatever device the tensors live on (host tensors use the reference's torch ops); the native pieces it
+calls (activations, optimizer step, rasterizer, distCUDA2) are HIP-only.
 """
 from __future__ import annotations
 
@@ -20,9 +31,20 @@ import torch
 from torch import nn
 
 from . import ply_io
+from .activations import ActivationCache
 
 SH_C0 = 0.28209479177387814
 GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")       # optimizer group order of the reference
+TABLE = ("xyz", "features", "opacity", "scaling", "rotation")              # this class's leaf tensors (features = f_dc | f_rest)
+
+
+def _pack(t: dict) -> dict:
+    """Reference-named tensors (f_dc [n,1,3], f_rest [n,M-1,3]) -> table-named ones (features [n,M,3])."""
+    if "features" in t:
+        return {k: t[k] for k in TABLE}
+    out = {k: t[k] for k in TABLE if k != "features"}
+    out["features"] = torch.cat((t["f_dc"], t["f_rest"]), dim=1)
+    return out
 
 
 @dataclass
@@ -78,7 +100,8 @@ class GaussianModel:
     def __init__(self, sh_degree: int):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree
-        self._t = {k: torch.empty(0) for k in GROUPS}
+        self._t = {k: torch.empty(0) for k in TABLE}
+        self._acts = ActivationCache()
         self.max_radii2D = torch.empty(0)
         self.xyz_gradient_accum = torch.empty(0)
         self.denom = torch.empty(0)
@@ -88,9 +111,11 @@ class GaussianModel:
         self.freeze_means = self.freeze_scales = self.freeze_rotations = self.freeze_opacities = False
 
     # ---- the reference's attribute names -------------------------------------------------------------------
+    packed_features = True                                   # _features_dc / _features_rest are views of _features
     _xyz = property(lambda s: s._t["xyz"])
-    _features_dc = property(lambda s: s._t["f_dc"])
-    _features_rest = property(lambda s: s._t["f_rest"])
+    _features = property(lambda s: s._t["features"])
+    _features_dc = property(lambda s: s._t["features"][:, :1])
+    _features_rest = property(lambda s: s._t["features"][:, 1:])
     _opacity = property(lambda s: s._t["opacity"])
     _scaling = property(lambda s: s._t["scaling"])
     _rotation = property(lambda s: s._t["rotation"])
@@ -101,22 +126,22 @@ class GaussianModel:
 
     @property
     def get_scaling(self):
-        s = torch.exp(self._scaling)
+        s = self._acts.get(0, self._scaling, self._rotation, self._opacity)
         return s.detach() if self.freeze_scales else s
 
     @property
     def get_rotation(self):
-        r = torch.nn.functional.normalize(self._rotation)
+        r = self._acts.get(1, self._scaling, self._rotation, self._opacity)
         return r.detach() if self.freeze_rotations else r
 
     @property
     def get_opacity(self):
-        o = torch.sigmoid(self._opacity)
+        o = self._acts.get(2, self._scaling, self._rotation, self._opacity)
         return o.detach() if self.freeze_opacities else o
 
     @property
     def get_features(self):
-        return torch.cat((self._features_dc, self._features_rest), dim=1)
+        return self._t["features"]                           # = torch.cat((_features_dc, _features_rest), dim=1), see the header
 
     def get_covariance(self, scaling_modifier=1):
         L = quat_to_rotmat(self._rotation) @ torch.diag_embed(self.get_scaling * scaling_modifier)
@@ -132,7 +157,9 @@ class GaussianModel:
 
     # ---- initialisation ------------------------------------------------------------------------------------
     def _adopt(self, tensors: dict):
-        self._t = {k: nn.Parameter(tensors[k].detach().clone().contiguous().requires_grad_(True)) for k in GROUPS}
+        tensors = _pack(tensors)
+        self._t = {k: nn.Parameter(tensors[k].detach().clone().contiguous().requires_grad_(True)) for k in TABLE}
+        self._acts.invalidate()
         P = self._xyz.shape[0]
         self.max_radii2D = torch.zeros(P, device=self.device)
 
@@ -166,12 +193,18 @@ class GaussianModel:
         self.denom = torch.zeros(P, 1, device=self.device)
         lrs = dict(xyz=opt.position_lr_init * self.spatial_lr_scale, f_dc=opt.feature_lr, f_rest=opt.feature_lr / 20.0,
                    opacity=opt.opacity_lr, scaling=opt.scaling_lr, rotation=opt.rotation_lr)
-        groups = [{"params": [self._t[k]], "lr": lrs[k], "name": k} for k in GROUPS]
-        if self.device.type == "cuda" and getattr(opt, "fused_adam", True):
-            from fused_adam import FusedAdam          # same state layout as torch.optim.Adam, one kernel per tensor
-            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
-        else:
-            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        # the reference's six groups, in its order; "f_dc" carries the interleaved SH table and takes the lr of its columns
+        # 1.. from the parameter-less group "f_rest" (see the header)
+        groups = []
+        for k in GROUPS:
+            if k == "f_dc":
+                groups.append({"params": [self._t["features"]], "lr": lrs[k], "name": k, "head_cols": 1, "tail": "f_rest"})
+            elif k == "f_rest":
+                groups.append({"params": [], "lr": lrs[k], "name": k})
+            else:
+                groups.append({"params": [self._t[k]], "lr": lrs[k], "name": k})
+        from fused_adam import FusedAdam              # torch.optim.Adam's arithmetic and state layout; one HIP kernel per tensor
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15, native=getattr(opt, "fused_adam", True) and self.device.type == "cuda")
         self._xyz_lr = expon_lr(opt.position_lr_init * self.spatial_lr_scale, opt.position_lr_final * self.spatial_lr_scale,
                                 lr_delay_mult=opt.position_lr_delay_mult, max_steps=opt.position_lr_max_steps)
 
@@ -183,12 +216,18 @@ class GaussianModel:
 
     # ---- one primitive for every structural edit -------------------------------------------------------------
     def _rebuild(self, keep=None, extra=None, replace=None):
-        """New parameter table = old rows selected by boolean `keep` (all if None), then `extra` rows appended;
-        `replace` = {group: tensor} swaps a whole tensor (fresh Adam moments).  Adam moments follow their rows;
+        """New parameter table = old rows selected by boolean `keep` (all if None), then `extra` rows appended
+        (`extra` names its tensors as the table does, or as the reference does with f_dc / f_rest);
+        `replace` = {name: tensor} swaps a whole tensor (fresh Adam moments).  Adam moments follow their rows;
         appended rows start with zero moments (the reference's _prune_optimizer / cat_tensors_to_optimizer /
         replace_tensor_to_optimizer in one pass)."""
+        if extra is not None:
+            extra = _pack(extra)
+        done = set()
         for grp in self.optimizer.param_groups if self.optimizer is not None else []:
-            name, old = grp["name"], grp["params"][0]
+            if not grp["params"]:
+                continue                                      # "f_rest": its columns live in the "f_dc" group's tensor
+            name, old = ("features" if grp["name"] == "f_dc" else grp["name"]), grp["params"][0]
             state = self.optimizer.state.pop(old, None)
             if replace is not None and name in replace:
                 new = replace[name]
@@ -207,12 +246,18 @@ class GaussianModel:
             if state is not None:
                 self.optimizer.state[new] = state
             self._t[name] = new
-        if self.optimizer is None:
-            for name in GROUPS:
+            done.add(name)
+        for name in TABLE:
+            if name in done:
+                continue
+            if replace is not None and name in replace:
+                rows = replace[name]
+            else:
                 rows = self._t[name].detach() if keep is None else self._t[name].detach()[keep]
                 if extra is not None:
                     rows = torch.cat((rows, extra[name]), 0)
-                self._t[name] = nn.Parameter(rows.contiguous().requires_grad_(True))
+            self._t[name] = nn.Parameter(rows.contiguous().requires_grad_(True))
+        self._acts.invalidate()
 
     def _reset_stats(self):
         P = self._xyz.shape[0]
@@ -253,7 +298,7 @@ class GaussianModel:
         hot = torch.norm(grads, dim=-1) >= max_grad
         # clone: small Gaussians with a large view-space gradient are duplicated in place
         sel = hot & ~big
-        self._rebuild(extra={k: self._t[k].detach()[sel] for k in GROUPS})
+        self._rebuild(extra={k: self._t[k].detach()[sel] for k in TABLE})
         n_after_clone = self._xyz.shape[0]
         self._reset_stats()
         # split: large ones are replaced by N = 2 samples from themselves, 1.6x smaller
@@ -263,7 +308,7 @@ class GaussianModel:
         scale_sel = self.get_scaling.detach()[sel].repeat(N, 1)
         offs = torch.normal(mean=torch.zeros_like(scale_sel), std=scale_sel)
         R = quat_to_rotmat(self._rotation.detach()[sel]).repeat(N, 1, 1)
-        new = {k: self._t[k].detach()[sel].repeat(N, *([1] * (self._t[k].dim() - 1))) for k in GROUPS}
+        new = {k: self._t[k].detach()[sel].repeat(N, *([1] * (self._t[k].dim() - 1))) for k in TABLE}
         new["xyz"] = torch.bmm(R, offs.unsqueeze(-1)).squeeze(-1) + self._xyz.detach()[sel].repeat(N, 1)
         new["scaling"] = torch.log(scale_sel / (0.8 * N))
         self._rebuild(extra=new)

@@ -1,0 +1,183 @@
+"""GPU tests of SURVEY 8a row a14, the producer side of the hot path: the native activations behind the reference
+GaussianModel's getters (scene/gaussian_model.py:101-125), the interleaved SH table behind get_features, and the
+split-lr Adam step that keeps the reference's "f_dc" / "f_rest" groups over that table.  torch's own ops ARE the
+reference here (the getters are torch.exp / F.normalize / torch.sigmoid / torch.cat), so they are the oracle:
+values within a few ulp, gradients within 1e-6 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+import scene_synth as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _raw(P, seed):
+    g = torch.Generator().manual_seed(seed)
+    scaling = (torch.randn(P, 3, generator=g) * 2.0 - 3.0)
+    rotation = torch.randn(P, 4, generator=g)
+    opacity = torch.randn(P, 1, generator=g) * 4.0
+    if P >= 8:
+        rotation[0] = 0.0                                  # |q| = 0: normalize divides by eps, gradient g / eps
+        rotation[1] = torch.tensor([1e-13, 0.0, 0.0, 0.0])  # below eps
+        rotation[2] = torch.tensor([3e-12, 0.0, 0.0, 0.0])  # just above eps
+        rotation[3] = torch.tensor([1e10, -1e10, 1e10, 1e10])
+        opacity[4], opacity[5] = 40.0, -40.0               # saturated sigmoid
+        scaling[6] = torch.tensor([-30.0, 0.0, 20.0])
+    return [t.to(DEV).requires_grad_(True) for t in (scaling, rotation, opacity)]
+
+
+@pytest.mark.parametrize("P", [1, 3, 1000, 100_003])
+def test_native_activations_match_torch(P):
+    from diff_gaussian_rasterization import _native as N
+    sc, ro, op = _raw(P, P)
+    want = (torch.exp(sc), torch.nn.functional.normalize(ro), torch.sigmoid(op))
+    got = N.activations_forward(sc.detach(), ro.detach(), op.detach())
+    for name, w, g in zip(("scales", "rotations", "opacities"), want, got):
+        assert g.shape == w.shape
+        err = (g - w.detach()).abs()
+        tol = 4 * torch.finfo(torch.float32).eps * w.detach().abs().clamp_min(1e-30)
+        assert bool((err <= tol).all()), (name, float((err / tol).max()))
+    gen = torch.Generator().manual_seed(P + 1)
+    grads = [torch.randn(*w.shape, generator=gen).to(DEV) for w in want]
+    torch.autograd.backward(want, grads)
+    d = N.activations_backward(got[0], ro.detach(), got[2], *grads)
+    for name, raw, mine in zip(("scaling", "rotation", "opacity"), (sc, ro, op), d):
+        ref = raw.grad
+        finite = torch.isfinite(ref)
+        assert bool((torch.isfinite(mine) == finite).all()), name
+        scale = float(ref[finite].abs().max()) if finite.any() else 1.0
+        err = (mine - ref)[finite].abs()
+        assert bool((err <= 1e-6 * scale + 1e-5 * ref[finite].abs()).all()), (name, float(err.max()), scale)
+    # a None gradient skips that tensor
+    d2 = N.activations_backward(got[0], ro.detach(), got[2], grads[0], None, grads[2])
+    assert d2[1] is None and torch.equal(d2[0], d[0]) and torch.equal(d2[2], d[2])
+
+
+def _models(P=4000, D=3, seed=9, W=200, H=136):
+    """The same scene in this package's GaussianModel (native getters, packed SH table) and in the plain parameter store
+    with the reference's torch getters."""
+    from gaussian_params import GaussianParams
+    from scene import GaussianModel
+    scene = S.make_scene(P, W, H, D, seed, scale_lo=0.01, scale_hi=0.08)
+    gm = GaussianModel(D)
+    gm.adopt_scene(scene, device=DEV)
+    gp = GaussianParams(scene.to(DEV)).to(DEV)
+    return gm, gp
+
+
+def test_model_getters_equal_the_reference_getters_and_their_gradients():
+    gm, gp = _models()
+    for name in ("get_xyz", "get_scaling", "get_rotation", "get_opacity", "get_features"):
+        a, b = getattr(gm, name), getattr(gp, name)
+        assert a.shape == b.shape and a.requires_grad, name
+        assert torch.allclose(a, b, rtol=1e-6, atol=0), name
+    gen = torch.Generator().manual_seed(0)
+    w = {n: torch.randn(*getattr(gp, n).shape, generator=gen).to(DEV) for n in ("get_scaling", "get_rotation", "get_opacity", "get_features")}
+    for m in (gm, gp):
+        sum((getattr(m, n) * w[n]).sum() for n in w).backward()
+    pairs = (("_scaling", gm._scaling.grad, gp._scaling.grad), ("_rotation", gm._rotation.grad, gp._rotation.grad),
+             ("_opacity", gm._opacity.grad, gp._opacity.grad),
+             ("_features_dc", gm._features.grad[:, :1], gp._features_dc.grad), ("_features_rest", gm._features.grad[:, 1:], gp._features_rest.grad))
+    for name, a, b in pairs:
+        assert (a - b).abs().max() <= 1e-6 * float(b.abs().max()), name
+
+
+def test_getters_share_one_evaluation_until_it_is_stale():
+    """One native evaluation serves the three getters of an iteration; it is dropped when its backward has run, when a
+    parameter changes (optimizer step, in-place edit, structural edit) and across grad modes."""
+    from diff_gaussian_rasterization import _native as N
+    from scene import OptimizationDefaults
+    gm, _ = _models(P=2000)
+    gm.training_setup(OptimizationDefaults())
+    N.profile_enable(True)
+    s, r, o = gm.get_scaling, gm.get_rotation, gm.get_opacity
+    assert gm.get_scaling is s and gm.get_opacity is o
+    torch.cuda.synchronize()
+    prof = N.profile_read()
+    assert prof["activations_fwd"][1] == 1, prof                   # three getters (five calls), one launch
+    (s.sum() + r.sum() + o.sum()).backward()
+    torch.cuda.synchronize()
+    assert N.profile_read()["activations_bwd"][1] == 1
+    N.profile_enable(False)
+    s2 = gm.get_scaling                                            # the used graph is not handed out again
+    assert s2 is not s and torch.equal(s2, s)
+    (s2.sum() * 2).backward()                                      # and a second backward works
+    with torch.no_grad():
+        s3 = gm.get_scaling
+        assert not s3.requires_grad and gm.get_scaling is s3
+    assert gm.get_scaling.requires_grad                            # grad mode is part of the key
+    before = gm.get_scaling.detach().clone()
+    for p in gm._t.values():
+        p.grad = torch.ones_like(p)
+    gm.optimizer.step()                                            # FusedAdam bumps the versions of what it wrote
+    after = gm.get_scaling
+    assert not torch.equal(after, before) and torch.allclose(after, torch.exp(gm._scaling))
+    with torch.no_grad():
+        gm._t["opacity"].fill_(0.0)
+    assert torch.equal(gm.get_opacity, torch.full_like(gm._opacity, 0.5))
+    gm.prune_points(torch.arange(2000, device=DEV) % 2 == 0)
+    assert gm.get_scaling.shape[0] == 1000 == gm.get_rotation.shape[0] == gm.get_features.shape[0]
+    gm.freeze_rotations = True
+    assert not gm.get_rotation.requires_grad and gm.get_scaling.requires_grad
+
+
+def test_render_from_the_model_equals_render_from_the_reference_getters():
+    """render() over GaussianModel (native getters, get_features = the packed table) against render() over the plain store
+    whose getters are the reference's torch ops: same image, same gradients on the raw parameters."""
+    from gaussian_params import Pipe
+    from gaussian_renderer import render
+    W, H = 200, 136
+    gm, gp = _models(P=6000, W=W, H=H)
+    cam, bg = S.make_camera(W, H).to(DEV), torch.tensor([0.1, 0.2, 0.3], device=DEV)
+    gimg = S.make_grad_image(W, H, 5).to(DEV)
+    outs = []
+    for m in (gm, gp):
+        out = render(cam, m, Pipe(), bg)
+        out["render"].backward(gimg)
+        outs.append(out)
+    a, b = outs
+    assert torch.equal(a["radii"], b["radii"])
+    assert (a["render"] - b["render"]).abs().max() <= 2e-6
+    assert (a["viewspace_points"].grad - b["viewspace_points"].grad).abs().max() <= 1e-5 * float(b["viewspace_points"].grad.abs().max())
+    pairs = (("_xyz", gm._xyz.grad, gp._xyz.grad), ("_scaling", gm._scaling.grad, gp._scaling.grad),
+             ("_rotation", gm._rotation.grad, gp._rotation.grad), ("_opacity", gm._opacity.grad, gp._opacity.grad),
+             ("_features_dc", gm._features.grad[:, :1], gp._features_dc.grad), ("_features_rest", gm._features.grad[:, 1:], gp._features_rest.grad))
+    for name, x, y in pairs:
+        assert (x - y).abs().max() <= 2e-5 * float(y.abs().max()) + 1e-9, (name, float((x - y).abs().max()), float(y.abs().max()))
+
+
+@pytest.mark.parametrize("M", [16, 9, 4, 1])
+def test_split_adam_equals_adam_on_the_two_tensors(M):
+    """gsr_adam_step_split over the packed table [P, M, 3] (group "f_dc" lr for column 0, group "f_rest" lr for the others)
+    against torch.optim.Adam over the reference's two tensors (scene/gaussian_model.py:166-168), and against the library's
+    own plain step on the two tensors, which it must equal bit for bit."""
+    from fused_adam import FusedAdam
+    torch.manual_seed(M)
+    P = 1237
+    table = torch.randn(P, M, 3, device=DEV)
+    dc, rest = table[:, :1].clone().requires_grad_(True), table[:, 1:].clone().requires_grad_(True)
+    dc2, rest2 = dc.detach().clone().requires_grad_(True), rest.detach().clone().requires_grad_(True)
+    packed = table.clone().requires_grad_(True)
+    two = [{"params": [dc], "lr": 0.0025, "name": "f_dc"}] + ([{"params": [rest], "lr": 0.000125, "name": "f_rest"}] if M > 1 else [])
+    two2 = [{"params": [dc2], "lr": 0.0025, "name": "f_dc"}] + ([{"params": [rest2], "lr": 0.000125, "name": "f_rest"}] if M > 1 else [])
+    ref = torch.optim.Adam(two, lr=0.0, eps=1e-15)
+    plain = FusedAdam(two2, lr=0.0, eps=1e-15)
+    fus = FusedAdam([{"params": [packed], "lr": 0.0025, "name": "f_dc", "head_cols": 1, "tail": "f_rest"},
+                     {"params": [], "lr": 0.000125, "name": "f_rest"}], lr=0.0, eps=1e-15)
+    for it in range(5):
+        g = torch.randn(P, M, 3, device=DEV) * (0.0 if it == 2 else 1.0)
+        dc.grad, dc2.grad, packed.grad = g[:, :1].clone(), g[:, :1].clone(), g.clone()
+        if M > 1:
+            rest.grad, rest2.grad = g[:, 1:].clone(), g[:, 1:].clone()
+        v0 = packed._version
+        ref.step(); plain.step(); fus.step()
+        assert packed._version > v0                                # autograd is told about the raw-pointer write
+    assert torch.equal(packed.detach()[:, :1], dc2.detach())
+    assert (packed.detach()[:, :1] - dc.detach()).abs().max() <= 2e-6 * float(dc.detach().abs().max())
+    if M > 1:
+        assert torch.equal(packed.detach()[:, 1:], rest2.detach())
+        assert (packed.detach()[:, 1:] - rest.detach()).abs().max() <= 2e-6 * float(rest.detach().abs().max())
+        assert (fus.state[packed]["exp_avg_sq"][:, 1:] - ref.state[rest]["exp_avg_sq"]).abs().max() <= 1e-6

@@ -56,7 +56,10 @@ def test_ply_round_trip_and_layout(tmp_path):
 def test_structural_edits_keep_adam_state_aligned():
     torch.manual_seed(0)
     gm = _model(400)
-    for p in gm.optimizer.param_groups:                      # one Adam step so that moments exist
+    groups = [g for g in gm.optimizer.param_groups if g["params"]]     # "f_rest" holds no tensor: its columns live in "f_dc"
+    assert [g["name"] for g in gm.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    table = lambda g: gm._t["features" if g["name"] == "f_dc" else g["name"]]
+    for p in groups:                                         # one Adam step so that moments exist
         p["params"][0].grad = torch.randn_like(p["params"][0])
     gm.optimizer.step()
     tag = gm._xyz.detach().clone()
@@ -67,9 +70,9 @@ def test_structural_edits_keep_adam_state_aligned():
     assert gm._xyz.shape[0] == 300 and gm.denom.shape[0] == 300 and gm.max_radii2D.shape[0] == 300
     assert torch.equal(gm._xyz.detach(), tag[~mask])
     assert torch.equal(gm.optimizer.state[gm._xyz]["exp_avg"], m_before[~mask])
-    for g in gm.optimizer.param_groups:
+    for g in groups:
         p = g["params"][0]
-        assert p.shape[0] == 300 and gm.optimizer.state[p]["exp_avg_sq"].shape == p.shape and p is gm._t[g["name"]]
+        assert p.shape[0] == 300 and gm.optimizer.state[p]["exp_avg_sq"].shape == p.shape and p is table(g)
     # opacity reset: opacities capped at 0.01, fresh moments
     gm.reset_opacity()
     assert float(gm.get_opacity.detach().max()) <= 0.01 + 1e-6
@@ -84,12 +87,60 @@ def test_structural_edits_keep_adam_state_aligned():
     n0 = gm._xyz.shape[0]
     gm.densify_and_prune(0.0002, 0.005, extent=5.0, max_screen_size=None)
     assert gm._xyz.shape[0] == n0 + 20 + 2 * 20 - 20 - 10    # +clones, +children, -parents, -transparent
-    for g in gm.optimizer.param_groups:
+    for g in groups:
         p = g["params"][0]
-        assert gm.optimizer.state[p]["exp_avg"].shape == p.shape
+        assert gm.optimizer.state[p]["exp_avg"].shape == p.shape and p is table(g)
     assert gm.xyz_gradient_accum.shape[0] == gm._xyz.shape[0] == gm.max_radii2D.shape[0]
     # capture / restore
     snap = gm.capture()
     gm3 = GaussianModel(3)
     gm3.restore(snap, OptimizationDefaults())
     assert torch.equal(gm3._xyz.detach(), gm._xyz.detach()) and gm3.active_sh_degree == gm.active_sh_degree
+
+
+def test_packed_features_behave_as_the_reference_two_tensors():
+    """get_features is the interleaved table itself (= torch.cat of its two column ranges, scene/gaussian_model.py:118-121);
+    _features_dc / _features_rest are views with the reference's shapes, and gradients through either reach the table."""
+    gm = _model(64)
+    F = gm.get_features
+    assert F is gm._features and F.shape == (64, 16, 3) and F.is_leaf and F.requires_grad
+    assert gm._features_dc.shape == (64, 1, 3) and gm._features_rest.shape == (64, 15, 3)
+    assert torch.equal(torch.cat((gm._features_dc, gm._features_rest), dim=1), F)
+    w = torch.randn(64, 16, 3)
+    (torch.cat((gm._features_dc, gm._features_rest), dim=1) * w).sum().backward()
+    assert torch.equal(F.grad, w)
+
+
+def test_adam_on_the_packed_table_equals_torch_adam_on_two_tensors():
+    """One optimizer step of the model (FusedAdam's torch arithmetic on host tensors; groups "f_dc" lr and "f_rest" lr
+    over one table) against torch.optim.Adam over the reference's six separate tensors (scene/gaussian_model.py:159-177)."""
+    torch.manual_seed(1)
+    gm = _model(128)
+    opt = OptimizationDefaults()
+    ref = {k: v.detach().clone().requires_grad_(True) for k, v in dict(
+        xyz=gm._xyz, f_dc=gm._features_dc, f_rest=gm._features_rest, opacity=gm._opacity, scaling=gm._scaling,
+        rotation=gm._rotation).items()}
+    lrs = dict(xyz=opt.position_lr_init * gm.spatial_lr_scale, f_dc=opt.feature_lr, f_rest=opt.feature_lr / 20.0,
+               opacity=opt.opacity_lr, scaling=opt.scaling_lr, rotation=opt.rotation_lr)
+    ref_opt = torch.optim.Adam([{"params": [ref[k]], "lr": lrs[k], "name": k} for k in ref], lr=0.0, eps=1e-15)
+    for it in range(3):
+        grads = {k: torch.randn_like(v) * 10.0 ** float(torch.randint(-6, 1, ())) for k, v in ref.items()}
+        for k, v in ref.items():
+            v.grad = grads[k].clone()
+        for k in ("xyz", "opacity", "scaling", "rotation"):
+            gm._t[k].grad = grads[k].clone()
+        gm._features.grad = torch.cat((grads["f_dc"], grads["f_rest"]), dim=1)
+        ref_opt.step(); gm.optimizer.step()
+        for k, attr in (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+                        ("scaling", "_scaling"), ("rotation", "_rotation")):
+            assert torch.equal(getattr(gm, attr).detach(), ref[k].detach()), (it, k)
+    m = gm.optimizer.state[gm._features]["exp_avg"]
+    assert torch.equal(m[:, :1], ref_opt.state[ref["f_dc"]]["exp_avg"]) and torch.equal(m[:, 1:], ref_opt.state[ref["f_rest"]]["exp_avg"])
+
+
+def test_getters_on_host_tensors_are_the_reference_torch_ops():
+    gm = _model(50)
+    assert torch.equal(gm.get_scaling, torch.exp(gm._scaling)) and torch.equal(gm.get_opacity, torch.sigmoid(gm._opacity))
+    assert torch.equal(gm.get_rotation, torch.nn.functional.normalize(gm._rotation))
+    gm.freeze_scales = True
+    assert not gm.get_scaling.requires_grad and gm.get_rotation.requires_grad
