@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg3n", "cfg3b", "cfg5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the non-saturating scene and the second seed")
+    ap.add_argument("--no-extras", action="store_true", help="skip the comparison passes (torch getters, fused activations, ...) "
+                    "and the profiled pass: the timed region only (for external profilers)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL process group, ShardedRenderer, slab-local loss) "
                          "with world_size 1")
@@ -119,7 +121,8 @@ def main():
 
     ctx = dict(dev=dev, dist=dist, world=world, rank=rank, sharded_on=(world > 1 or args.force_sharded))
     single = world == 1 and not args.force_sharded
-    m = measure(args.workload, args.steps, args.warmup, ctx, extras=single, traffic=(args.workload == "cfg3" and world == 1))
+    m = measure(args.workload, args.steps, args.warmup, ctx, extras=single and not args.no_extras, traffic=(args.workload == "cfg3" and world == 1),
+                profile=not args.no_extras)
 
     if rank != 0:
         if dist is not None:
