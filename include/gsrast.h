@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 9
+#define GSR_VERSION 10
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -65,7 +65,7 @@ typedef struct gsr_frame_plan {
                                                      emitted; <= the reference's num_rendered                */
     int32_t num_visible;                          /* V: Gaussians with radius > 0                           */
     int32_t num_chunks;                           /* depth chunks planned (1..GSR_MAX_CHUNKS)               */
-    int32_t chunk_rank_begin[GSR_MAX_CHUNKS + 1]; /* chunk c = depth ranks [begin[c], begin[c+1])           */
+    int32_t chunk_rank_begin[GSR_MAX_CHUNKS + 1]; /* chunk c = positions [begin[c], begin[c+1]) of the depth order */
     int64_t chunk_instances_max[GSR_MAX_CHUNKS];  /* instances of chunk c if every tile were open           */
     int32_t chunks_run;                           /* out of gsr_forward_render: chunks actually processed   */
     int32_t sort_result;                          /* out of gsr_forward_render: radix buffer holding lists  */
@@ -76,6 +76,11 @@ typedef struct gsr_frame_plan {
     int32_t screen_prezeroed;                     /* set by gsr_backward_prepare: screen_grads is already all zero   */
     int64_t binning_capacity;                     /* IN to gsr_forward_render (and the backward): instances the binning
                                                      workspace was sized for (gsr_binning_size of that number); 0 = R   */
+    uint32_t chunk_key_end[GSR_MAX_CHUNKS];       /* chunk c = visible Gaussians whose depth bits lie in (key_end[c-1], key_end[c]]:
+                                                     the chunks are SELECTED by depth; each is sorted when it is binned  */
+    int32_t chunks_sorted;                        /* chunks [0, chunks_sorted) of the depth order are already sorted: a re-run of
+                                                     gsr_forward_render (after GSR_ERR_WORKSPACE) does not sort them again   */
+    int32_t reserved_;
 } gsr_frame_plan;
 
 typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */
@@ -173,6 +178,23 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
 int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g,
                       const int32_t *radii, const void *geom_ws, const float *screen_grads, int32_t g_begin,
                       int32_t g_end, int32_t binned_ranks, const gsr_grads *out, void *stream);
+
+/* gsr_backward_geom for an explicit list of Gaussians: the sparse geometry backward visits rows[0 .. n_rows) (device,
+ * Gaussian indices) instead of the frame's own binned depth prefix; every other row of the outputs must already be zero
+ * (gsr_backward_prepare) or is cleared first.  n_rows * 4 >= P runs the dense kernel over all P.  This is what a rank of
+ * a tile-row-sharded render calls after the ranks have summed their screen-space gradients: the list is then the union
+ * of what the ranks binned (all Gaussians whose depth key is <= the largest chunk end any rank reached). */
+int gsr_backward_geom_rows(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, const int32_t *radii,
+                           const void *geom_ws, const float *screen_grads, const int32_t *rows, int32_t n_rows, const gsr_grads *out,
+                           void *stream);
+
+/* Device pointers into a frame's geometry workspace (valid after gsr_forward_preprocess):
+ *   depth_keys [P]  by Gaussian: the bits of its view depth (a positive binary32: ordered as an integer), 0xFFFFFFFF = not
+ *                   visible.  Identical on every rank of a sharded render (visibility is that of the full image).
+ *   depth_order [P] the depth order: plan->chunk_rank_begin[c] .. [c+1] holds chunk c's Gaussians, sorted by (depth, index)
+ *                   for the chunks gsr_forward_render has run.
+ * Either may be NULL (not wanted). */
+int gsr_frame_arrays(const gsr_frame_desc *desc, const void *geom_ws, const uint32_t **depth_keys, const uint32_t **depth_order);
 
 /* `_C.mark_visible`: present[i] = 1 iff Gaussian i passes the near-plane test (A.1). */
 int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

@@ -238,9 +238,9 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     plan->num_chunks = 1;
     if (f.P == 0) return GSR_OK;
     GeomWS gw = carve_geom(geom_ws, f.P);
+    GSR_HIP_CHECK(hipMemsetAsync(gw.sel, 0, sizeof(SelState), s));       // the selection's histograms
     if ((rc = launch_preprocess(f, *cam, *g, gw, radii, desc->prefiltered != 0, dbg, s))) return rc;
-    if ((rc = launch_depth_order(f, gw, dbg, s))) return rc;
-    if ((rc = launch_chunk_plan(f, gw, dbg, s))) return rc;
+    if ((rc = launch_depth_select(f, gw, dbg, s))) return rc;           // chunk plan + partition by chunk (gsr_select.hip)
     if (image_ws) {                                  // stage 2's reset of ranges / open flags, in the shadow of the readback
         ImageWS iw = carve_image(image_ws, f);
         if ((rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
@@ -264,6 +264,7 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     plan->num_chunks = h.num_chunks > 0 ? (int32_t)h.num_chunks : 1;
     for (int c = 0; c <= GSR_MAX_CHUNKS; ++c) plan->chunk_rank_begin[c] = (int32_t)h.bnd[c];
     for (int c = 0; c < GSR_MAX_CHUNKS; ++c) plan->chunk_instances_max[c] = (int64_t)h.chunk_full[c];
+    for (int c = 0; c < GSR_MAX_CHUNKS; ++c) plan->chunk_key_end[c] = h.key_end[c];
     if (h.num_chunks == 0)
         for (int c = 0; c <= GSR_MAX_CHUNKS; ++c) plan->chunk_rank_begin[c] = 0;
     return GSR_OK;
@@ -317,6 +318,12 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
                       "binning_capacity = num_rendered (%lld)", (long long)capacity, c,
                       (unsigned long long)(emitted_before + (uint64_t)plan->chunk_instances_max[c]), (long long)plan->num_rendered);
             return GSR_ERR_WORKSPACE;
+        }
+        // the chunk's Gaussians were selected by depth; now that it is needed, put them in (depth, index) order
+        // (once: a re-run of this stage after GSR_ERR_WORKSPACE finds the earlier chunks sorted, and the sort's inputs consumed)
+        if (c >= plan->chunks_sorted) {
+            if ((rc = launch_chunk_order(f, r0, r1, c > 0 ? plan->chunk_key_end[c - 1] : 0u, plan->chunk_key_end[c], c == 0, gw, dbg, s))) return rc;
+            plan->chunks_sorted = c + 1;
         }
         if ((rc = launch_chunk_binning(f, c, r0, r1, (uint64_t)plan->chunk_instances_max[c], emitted_before, gw, bw, iw, &sort_result,
                                        dbg, s)))
@@ -414,6 +421,33 @@ int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const g
     GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
     return launch_geom_bwd(f, *cam, *g, radii, gw, screen_grads, g_begin, g_end, binned_ranks, *out, desc->debug != 0,
                            (hipStream_t)stream);
+}
+
+int gsr_backward_geom_rows(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, const int32_t *radii,
+                           const void *geom_ws, const float *screen_grads, const int32_t *rows, int32_t n_rows, const gsr_grads *out,
+                           void *stream)
+{
+    int rc = validate(desc);
+    if (rc) return rc;
+    if ((rc = validate_inputs(desc, cam, g))) return rc;
+    if (!out || n_rows < 0 || n_rows > desc->P || (n_rows > 0 && !rows)) { set_error("gsr_backward_geom_rows: bad argument"); return GSR_ERR_INVALID_ARGUMENT; }
+    if (desc->P == 0) return GSR_OK;
+    if (!radii || !geom_ws || !screen_grads) { set_error("gsr_backward_geom_rows: NULL argument"); return GSR_ERR_INVALID_ARGUMENT; }
+    const FrameK f = make_frame(*desc);
+    GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
+    return launch_geom_bwd(f, *cam, *g, radii, gw, screen_grads, 0, f.P, n_rows, *out, desc->debug != 0, (hipStream_t)stream,
+                           reinterpret_cast<const uint32_t *>(rows));
+}
+
+int gsr_frame_arrays(const gsr_frame_desc *desc, const void *geom_ws, const uint32_t **depth_keys, const uint32_t **depth_order)
+{
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (!geom_ws) { set_error("gsr_frame_arrays: NULL workspace"); return GSR_ERR_INVALID_ARGUMENT; }
+    GeomWS gw = carve_geom(const_cast<void *>(geom_ws), desc->P);
+    if (depth_keys) *depth_keys = gw.sort_keys[0];
+    if (depth_order) *depth_order = gw.order;
+    return GSR_OK;
 }
 
 int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

@@ -35,11 +35,11 @@ namespace gsr {
 // closed at a mean of 1.9 cut-off depths, 99 % at 3.3 and the last one at 4.0-4.3 (measured with the oracle on cfg2,
 // cfg3, a second seed and off-axis cameras: the mass counts the faint skirts below alpha = 1/255 that the blend
 // skips, hence > 1).  5 leaves a margin; regions the splats cover unevenly simply close in the next, 4x larger, chunk.
-constexpr float kCutoffOpticalDepth = 9.2103404f;   // -ln(GSR_T_CUTOFF)
-constexpr float kChunkOpticalDepths = 5.f;
-constexpr uint32_t kMinFirstChunk = 1u << 18;    // ... but no chunk smaller than this many upper-bound instances (x4 per chunk):
+// (now in gsr_internal.h) constexpr float kCutoffOpticalDepth = 9.2103404f;
+// (now in gsr_internal.h) constexpr float kChunkOpticalDepths = 5.f;
+// (now in gsr_internal.h) constexpr uint32_t kMinFirstChunk = 1u << 18;
                                                  // a chunk's fixed cost is worth a few hundred thousand instances
-constexpr int kChunkGrowthLog2 = 2;              // x4 per chunk
+// (now in gsr_internal.h) constexpr int kChunkGrowthLog2 = 2;
 
 GeomWS carve_geom(void *base, int P)
 {
@@ -50,6 +50,7 @@ GeomWS carve_geom(void *base, int P)
     w.records = (float4 *)(b + o); o += align_up(Pn * 48);
     w.tiles_mass = (uint2 *)(b + o); o += align_up(Pn * 8);
     w.mass_blocks = (unsigned long long *)(b + o); o += align_up(((Pn + kScanTileElems - 1) / kScanTileElems + 1) * 8);
+    w.sel = (SelState *)(b + o); o += align_up(sizeof(SelState));
     w.clamped = (uint8_t *)(b + o); o += align_up(Pn);
     for (int i = 0; i < 2; ++i) { w.sort_keys[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
     for (int i = 0; i < 2; ++i) { w.sort_vals[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
@@ -98,157 +99,6 @@ BinningWS carve_binning(void *base, int64_t R)
 }
 
 constexpr int kBinBlock = 256;
-
-// ---- depth order: sort (depth bits, Gaussian) pairs written by the preprocess kernel, then scan the tile counts
-// in depth order (the scan gathers tiles[order[r]] itself).
-int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
-{
-    if (f.P == 0) return GSR_OK;
-    int result = 0, rc;
-    if ((rc = launch_radix_sort<uint32_t>(ws.sort_keys, ws.sort_vals, nullptr, (uint32_t)f.P, (uint64_t)f.P, nullptr, 0, 32,
-                                          ws.radix_temp, &result, "depth_sort", debug, s)))
-        return rc;
-    if (result != 0) { set_error("internal: depth sort result buffer %d", result); return GSR_ERR_HIP; }
-    return launch_scan_inclusive(nullptr, ws.offs_full, f.P, ws.scan_temp, &ws.ctrl->R_total, nullptr, nullptr, "scan_tiles",
-                                 debug, s, &ws.ctrl->overflow, ws.order, ws.tiles_mass, ws.mass_blocks);
-}
-
-// ---- chunk plan (one block of 9 waves): wave 0 finds V (first rank whose key is 0xFFFFFFFF), wave 1+c the end
-// of chunk c (first rank whose inclusive tile count exceeds the chunk's cumulative target: first, 4 first,
-// 16 first, ... with the last chunk taking everything that is left).  Each wave runs a 64-ary search, so the
-// dependent-load chain is 4 deep at a million Gaussians instead of 20.
-template <typename Pred>
-__device__ __forceinline__ uint32_t wave_lower_bound(uint32_t n, Pred pred)   // first i in [0,n) with pred(i), else n
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint32_t step = (hi - lo + 63u) >> 6;
-        const uint32_t seg = lo + lane * step;
-        const bool valid = seg < hi;
-        const uint32_t last = valid ? min(hi, seg + step) - 1u : 0u;            // last element of this lane's segment
-        const unsigned long long m = __ballot(valid && pred(last));
-        if (m == 0ull) return hi;
-        const uint32_t k = (uint32_t)__ffsll((long long)m) - 1u;
-        hi = __shfl(last, (int)k);
-        lo = lo + k * step;
-    }
-    return lo;
-}
-
-// First depth rank (+1) at which the running optical mass exceeds `target`: the 2048-rank block from the block prefix
-// (64-ary search), then that block's ranks 64 at a time.
-__device__ __forceinline__ uint32_t wave_mass_end(int P, unsigned long long target, const uint32_t *__restrict__ order,
-                                                  const uint2 *__restrict__ mass, const unsigned long long *__restrict__ blocks)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nb = (uint32_t)((P + kScanTileElems - 1) / kScanTileElems);
-    if (blocks[nb] <= target) return (uint32_t)P;                                  // the whole frame stays below
-    const uint32_t b = wave_lower_bound(nb, [&](uint32_t i) { return blocks[i + 1] > target; });
-    // inside the block: every lane sums 32 consecutive ranks (32 independent gathers in flight per lane: two memory
-    // latencies in all, not 64), the wave scans the 64 lane sums, and the lane that holds the crossing walks its 32 values
-    constexpr int kPerLane = kScanTileElems / kWave;
-    const uint32_t r0 = b * (uint32_t)kScanTileElems + lane * (uint32_t)kPerLane;
-    uint32_t mv[kPerLane];
-    unsigned long long mine = 0;
-#pragma unroll
-    for (int i = 0; i < kPerLane; ++i) {
-        const uint32_t r = r0 + (uint32_t)i;
-        mv[i] = r < (uint32_t)P ? mass[order[r]].y : 0u;
-        mine += mv[i];
-    }
-    unsigned long long inc = mine;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const unsigned long long t = __shfl_up(inc, off);
-        if ((int)lane >= off) inc += t;
-    }
-    const unsigned long long before = blocks[b] + inc - mine;                      // running mass in front of this lane's ranks
-    const unsigned long long m = __ballot(before + mine > target);
-    if (m == 0ull) return min((uint32_t)P, (b + 1u) * (uint32_t)kScanTileElems);   // cannot happen (blocks[b + 1] > target)
-    const int owner = __ffsll((long long)m) - 1;
-    uint32_t end = 0;
-    if ((int)lane == owner) {
-        unsigned long long run = before;
-        bool found = false;
-        end = r0 + (uint32_t)kPerLane;
-#pragma unroll
-        for (int i = 0; i < kPerLane; ++i) {                                       // constant indices: mv stays in registers
-            run += mv[i];
-            if (!found && run > target) { end = r0 + (uint32_t)i + 1u; found = true; }    // include the crossing rank
-        }
-    }
-    end = (uint32_t)__shfl((int)end, owner);
-    return min((uint32_t)P, end);
-}
-
-__global__ __launch_bounds__(kWave *(GSR_MAX_CHUNKS + 1)) void k_chunk_plan(int P, unsigned long long first_mass, const uint32_t *__restrict__ sorted_keys,
-                                                                            const uint32_t *__restrict__ offs_full,
-                                                                            const uint32_t *__restrict__ order, const uint2 *__restrict__ mass,
-                                                                            const unsigned long long *__restrict__ mass_blocks, Ctrl *ctrl)
-{
-    __shared__ uint32_t sh_V, sh_end[GSR_MAX_CHUNKS];
-    const uint32_t R = ctrl->R_total;
-    const int w = threadIdx.x >> 6;
-    if (w == 0) {
-        const uint32_t V = wave_lower_bound((uint32_t)P, [&](uint32_t i) { return sorted_keys[i] == 0xFFFFFFFFu; });
-        if ((threadIdx.x & 63) == 0) sh_V = V;
-    } else {
-        // invisible Gaussians have a tile count and a mass of 0, so both running sums are flat beyond V: searching
-        // [0,P) and clamping to V gives the same answer as searching [0,V)
-        const int c = w - 1;
-        uint32_t end = (uint32_t)P;
-        if (c < GSR_MAX_CHUNKS - 1) {
-            end = wave_mass_end(P, first_mass << (kChunkGrowthLog2 * c), order, mass, mass_blocks);
-            const uint64_t floor_inst = (uint64_t)kMinFirstChunk << (kChunkGrowthLog2 * c);
-            if (floor_inst >= (uint64_t)R) end = (uint32_t)P;
-            else if (end < (uint32_t)P) {
-                const uint32_t e2 = wave_lower_bound((uint32_t)P, [&](uint32_t i) { return (uint64_t)offs_full[i] > floor_inst; });
-                end = max(end, e2);
-            }
-        }
-        if ((threadIdx.x & 63) == 0) sh_end[c] = end;
-    }
-    __syncthreads();
-    // chunk boundaries are a short integer recurrence over the searched ends: every one of the first GSR_MAX_CHUNKS threads
-    // replays it and then fetches its own chunk's instance bound, so the 2 x 8 dependent global loads happen side by side
-    const int c = threadIdx.x;
-    if (c >= GSR_MAX_CHUNKS) return;
-    const uint32_t V = sh_V;
-    uint32_t begin = 0, end = 0, nchunks = 0, my_begin = 0, my_end = 0;
-    bool mine = false;
-    for (int k = 0; k < GSR_MAX_CHUNKS && begin < V; ++k) {
-        end = sh_end[k];
-        if (end <= begin) end = begin + 1;               // every chunk makes progress
-        if (end > V) end = V;
-        if (k == c) { my_begin = begin; my_end = end; mine = true; }
-        begin = end;
-        nchunks = (uint32_t)k + 1;
-    }
-    ctrl->bnd[c + 1] = mine ? my_end : V;
-    ctrl->chunk_full[c] = mine ? offs_full[my_end - 1] - (my_begin ? offs_full[my_begin - 1] : 0u) : 0u;
-    ctrl->chunk_R[c] = 0;
-    ctrl->chunk_base[c + 1] = 0;
-    if (c == 0) {
-        ctrl->V = V;
-        ctrl->open_count = 0;
-        ctrl->bnd[0] = 0;
-        ctrl->chunk_base[0] = 0;
-        ctrl->num_chunks = nchunks;
-    }
-}
-
-int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
-{
-    ProfileScope prof("chunk_plan", s);
-    const double slab_px = (double)(f.ty1 - f.ty0) * GSR_TILE * (double)f.Gx * GSR_TILE;
-    const unsigned long long first_mass =
-        (unsigned long long)((double)kChunkOpticalDepths * kCutoffOpticalDepth * slab_px * (double)kMassUnitsPerPixelNeper) + 1ull;
-    hipLaunchKernelGGL(k_chunk_plan, dim3(1), dim3(kWave * (GSR_MAX_CHUNKS + 1)), 0, s, f.P, first_mass, ws.sort_keys[0], ws.offs_full, ws.order,
-                       ws.tiles_mass, ws.mass_blocks, ws.ctrl);
-    GSR_LAUNCH_CHECK("chunk_plan", debug, s);
-    return GSR_OK;
-}
 
 // ---- open flags: (re)initialise for the slab, count the tiles that are still open and pack the flags into one
 // bit per tile (row-major, ceil(Gx/64) words per tile row) for the count / emit kernels (one block).
@@ -302,8 +152,7 @@ int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hip
 // it scans the masks' popcounts and expands them into (tile, slot, Gaussian) triples in rectangle order.
 __device__ __forceinline__ uint32_t mask_base(const uint32_t *__restrict__ offs_full, int r0, int r, uint32_t total)
 {
-    const uint32_t cb = r0 > 0 ? offs_full[r0 - 1] : 0u;
-    const uint32_t start = offs_full[r] - total - cb;          // first candidate of rank r inside the chunk
+    const uint32_t start = offs_full[r] - total;               // first candidate of rank r inside the chunk (the scan restarts per chunk)
     return (start >> 6) + (uint32_t)(r - r0);                  // disjoint ranges of ceil(total / 64) words per rank
 }
 

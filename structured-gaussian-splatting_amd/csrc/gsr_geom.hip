@@ -107,9 +107,9 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
     records[3 * (size_t)i + 2] = make_float4(o.s.b, o.s.depth, o.s.rect_x, o.s.rect_y);
     // depth-sort key: binary32 pattern of the (positive) view depth; invisible Gaussians sort last.  Visibility
     // is that of the FULL image (radius > 0), not of this rank's slab, so that the depth order is identical on
-    // every rank of a sharded render (the multi-GPU gradient exchange indexes by depth rank).
+    // every rank of a sharded render (the multi-GPU gradient exchange selects by depth key).
     sort_keys[i] = o.radius > 0 ? __float_as_uint(o.s.depth) : 0xFFFFFFFFu;
-    sort_vals[i] = (uint32_t)i;
+    (void)sort_vals;                           // the depth order is built by selection (gsr_select.hip)
 }
 
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
@@ -566,9 +566,11 @@ int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, 
 }
 
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
-                    const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s)
+                    const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s,
+                    const uint32_t *rows)
 {
     if (g1 <= g0) return GSR_OK;
+    if (!rows) rows = gw.order;                  // the frame's own binned prefix
     if (n_ranks >= 0 && g0 == 0 && g1 == f.P && (long long)n_ranks * 4 < (long long)f.P) {
         // depth-complex frame: almost every gradient row is zero -> memset the outputs, then visit the binned prefix only
         ProfileScope prof("geom_bwd", s);
@@ -577,7 +579,7 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
         if (n_ranks > 0) {
             const int sgrid = (n_ranks + kGeomBlock - 1) / kGeomBlock;
 #define GSR_GS(DEG, RAW)                                                                                                     \
-    hipLaunchKernelGGL((k_geom_bwd_sparse<DEG, RAW>), dim3(sgrid), dim3(kGeomBlock), 0, s, f, n_ranks, gw.order, cam.viewmatrix, \
+    hipLaunchKernelGGL((k_geom_bwd_sparse<DEG, RAW>), dim3(sgrid), dim3(kGeomBlock), 0, s, f, n_ranks, rows, cam.viewmatrix, \
                        cam.projmatrix, cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs,      \
                        g.shs_rest, g.colors_precomp ? 1 : 0, radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads),   \
                        out)

@@ -67,9 +67,35 @@ inline FrameK make_frame(const gsr_frame_desc &d)
 }
 
 // ---- workspace carving (all sub-arrays 256-B aligned; the caller's base is torch-allocated, 512-B aligned)
+// ---- depth selection (gsr_select.hip): two-level histogram of the depth keys, chunk rule, stable partition by chunk
+constexpr int kSelBins = 2048;           // bins per level
+constexpr int kSelShift1 = 20;           // level 1: key >> 20 (positive float bits < 2^31: 2040 bins in use, 8 per binade)
+constexpr int kSelShift2 = 9;            // level 2: the next 11 bits -> sub-bins of 512 key codes (6e-5 relative depth)
+constexpr int kSelRefine = 2;            // chunk boundaries refined at level 2: the ends of chunks 0 and 1
+constexpr int kSelBlocks = 256;
+// the chunk rule (see gsr_binning.hip's header): chunk c ends where the running optical mass passes
+// kChunkOpticalDepths x ln(1e4) per slab pixel x 4^c and the running tile count passes kMinFirstChunk x 4^c
+constexpr float kCutoffOpticalDepth = 9.2103404f;   // -ln(GSR_T_CUTOFF)
+constexpr float kChunkOpticalDepths = 5.f;
+constexpr uint32_t kMinFirstChunk = 1u << 18;
+constexpr int kChunkGrowthLog2 = 2;              // x4 per chunk
+struct SelTables { uint32_t cnt[kSelBins]; unsigned long long tiles[kSelBins], mass[kSelBins]; };
+struct SelState {               // device scratch of the selection (zeroed at the start of every frame)
+    SelTables t1, t2[kSelRefine];
+    uint32_t bin[kSelRefine], base_cnt[kSelRefine];
+    unsigned long long base_tiles[kSelRefine], base_mass[kSelRefine];
+    uint32_t coarse_bin[GSR_MAX_CHUNKS], coarse_cnt[GSR_MAX_CHUNKS];
+    unsigned long long coarse_tiles[GSR_MAX_CHUNKS];
+    uint32_t V, pad_;
+    unsigned long long R;
+    uint32_t done[2];           // tickets of the two histogram kernels: their last block runs the plan step
+    uint32_t blk_cnt[GSR_MAX_CHUNKS][kSelBlocks];
+};
+
 struct Ctrl {                   // small device-side control block of one frame
     uint32_t R_total, V, num_chunks, open_count;
-    uint32_t bnd[GSR_MAX_CHUNKS + 1];          // depth-rank boundaries of the chunks
+    uint32_t bnd[GSR_MAX_CHUNKS + 1];          // boundaries of the chunks in the depth order
+    uint32_t key_end[GSR_MAX_CHUNKS];          // chunk c holds the visible Gaussians with depth bits in (key_end[c-1], key_end[c]]
     uint32_t chunk_full[GSR_MAX_CHUNKS];       // instances of the chunk if every tile were open
     uint32_t chunk_R[GSR_MAX_CHUNKS];          // instances actually emitted
     uint32_t chunk_base[GSR_MAX_CHUNKS + 1];   // first absolute instance index of the chunk
@@ -80,12 +106,14 @@ struct GeomWS {                 // O(P): the reference's geomBuffer
     float4 *records;            // [P,3]  Splat records, by Gaussian
     uint2 *tiles_mass;          // [P]    by Gaussian: .x = tiles touched, .y = optical mass inside the slab in 1/64 pixel-neper
                                 //        units (gsr_math.h optical_mass): one 8-byte gather in the depth-order scan
-    unsigned long long *mass_blocks;   // [ceil(P / 2048) + 1] exclusive prefix, in depth order, of the mass per 2048-rank block
+    unsigned long long *mass_blocks;   // [ceil(P / 2048) + 1] scratch of the tile-count scan (per-block sums of the pairs' second half)
+    SelState *sel;              // depth selection scratch
     uint8_t *clamped;           // [P]    by Gaussian
-    uint32_t *sort_keys[2];     // [P] x2 depth bits (0xFFFFFFFF = invisible)
-    uint32_t *sort_vals[2];     // [P] x2 Gaussian index; after the sort: depth rank -> Gaussian
-    uint32_t *order;            // alias of the sorted sort_vals buffer
-    uint32_t *offs_full;        // [P]    inclusive scan of the tiles touched, in depth order
+    uint32_t *sort_keys[2];     // [P] x2 [0]: depth bits by Gaussian (0xFFFFFFFF = invisible), kept; [1]: chunk-sort scratch
+    uint32_t *sort_vals[2];     // [P] x2 [0] = order; [1]: chunk-sort scratch
+    uint32_t *order;            // [P]    the depth order: chunk c at [bnd[c], bnd[c+1]), in (depth, index) order once the
+                                //        chunk has been binned, in index order before; beyond V: unspecified
+    uint32_t *offs_full;        // [P]    by position: inclusive scan of the tiles touched, restarting at every chunk
     uint32_t *cnt_open;         // [P]    by rank: instances emitted for this Gaussian
     uint32_t *offs_open;        // [P]    by rank: inclusive scan of cnt_open inside its chunk
     uint32_t *row_begin;        // [P]    by rank: absolute index of the Gaussian's first instance
@@ -133,13 +161,13 @@ int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, 
 template <typename K>
 int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
                       const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,
-                      bool debug, hipStream_t s);
+                      bool debug, hipStream_t s, bool even_passes = false);
 
 // ---- kernel launchers (each returns a gsr_status)
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
                       bool prefiltered, bool debug, hipStream_t s);
-int launch_depth_order(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
-int launch_chunk_plan(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
+int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
+int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_t key_hi, bool first, GeomWS &ws, bool debug, hipStream_t s);
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
 int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, int num_visible, GeomWS &ws,
                         bool debug, hipStream_t s);
@@ -155,7 +183,8 @@ int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, 
 int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
                        float *screen_grads, bool prezeroed, bool debug, hipStream_t s);
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
-                    const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s);
+                    const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s,
+                    const uint32_t *rows = nullptr);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 
 }  // namespace gsr

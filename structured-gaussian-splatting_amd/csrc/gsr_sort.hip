@@ -496,7 +496,7 @@ size_t radix_temp_bytes() { return align_up((size_t)kRadixBins * kRadixMaxBlocks
 template <typename K>
 int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
                       const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,
-                      bool debug, hipStream_t s)
+                      bool debug, hipStream_t s, bool even_passes)
 {
     *result = 0;
     if (n_max == 0 || end_bit <= begin_bit) return GSR_OK;
@@ -510,7 +510,9 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
     int cur = 0;
     // digits: as few passes as 8-bit digits need, the key bits spread evenly over them (13 tile-id bits sort as
     // 7 + 6, not 8 + 5: fewer bins in the first pass means longer contiguous runs in its scatter)
-    const int total_bits = end_bit - begin_bit, passes = (total_bits + 7) / 8;
+    const int total_bits = end_bit - begin_bit;
+    int passes = (total_bits + 7) / 8;
+    if (even_passes && (passes & 1)) ++passes;          // the caller wants the result back in buffer 0 (a 0-bit pass copies)
     int shift = begin_bit;
     for (int p = 0; p < passes; ++p) {
         const int left = end_bit - shift, bits = (left + (passes - p) - 1) / (passes - p);
@@ -533,8 +535,8 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
 }
 
 template int launch_radix_sort<uint32_t>(uint32_t *const[2], uint32_t *const[2], const uint32_t *, uint32_t, uint64_t,
-                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t);
+                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t, bool);
 template int launch_radix_sort<uint64_t>(uint64_t *const[2], uint32_t *const[2], const uint32_t *, uint32_t, uint64_t,
-                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t);
+                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t, bool);
 
 }  // namespace gsr

@@ -255,10 +255,12 @@ def prepare_backward(fr: "_Frame", needs) -> None:
 
 
 def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int = 0, g1: Optional[int] = None,
-                            binned_ranks: Optional[int] = None):
+                            binned_ranks: Optional[int] = None, rows: Optional[torch.Tensor] = None):
     """K8 + K9 on Gaussians [g0, g1).  `needs` = (means3D, means2D, sh, colors, opacities, scales, rotations,
     cov3D[, sh_rest]) booleans.  Returns the 8 gradient tensors (None where not needed / not applicable); for a
-    raw-mode frame 9: sh is then d/d_features_dc [P,1,3] and the ninth d/d_features_rest [P,M-1,3]."""
+    raw-mode frame 9: sh is then d/d_features_dc [P,1,3] and the ninth d/d_features_rest [P,M-1,3].
+    rows (int32 device tensor, whole range only): the Gaussians that can have a non-zero screen gradient, when that is not
+    the frame's own binned prefix (a sharded render: the union over the ranks)."""
     P, dev = fr.desc.P, fr.device
     g1 = P if g1 is None else g1
     partial = (g0, g1) != (0, P)
@@ -270,10 +272,14 @@ def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int =
     g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, g_rest = tensors
     if P > 0 and g1 > g0:
         with torch.cuda.device(dev):
-            if binned_ranks is None:        # gradients of this very frame: its own binned depth prefix
+            if rows is not None and not partial:
+                N.backward_geom_rows(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, rows, grads, dev)
+                binned_ranks = -2
+            elif binned_ranks is None:        # gradients of this very frame: its own binned depth prefix
                 plan = fr.plan
                 binned_ranks = int(plan.chunk_rank_begin[plan.chunks_run]) if plan.num_rendered > 0 and plan.chunks_run > 0 else 0
-            N.backward_geom(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, g0, g1, grads, dev, binned_ranks)
+            if binned_ranks != -2:
+                N.backward_geom(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, g0, g1, grads, dev, binned_ranks)
     if fr.raw:
         return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, g_rest
     return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov

@@ -51,7 +51,8 @@ class FramePlan(C.Structure):
     _fields_ = [("num_rendered", C.c_int64), ("num_visible", C.c_int32), ("num_chunks", C.c_int32),
                 ("chunk_rank_begin", C.c_int32 * (MAX_CHUNKS + 1)), ("chunk_instances_max", C.c_int64 * MAX_CHUNKS),
                 ("chunks_run", C.c_int32), ("sort_result", C.c_int32), ("instances_emitted", C.c_int64),
-                ("binning_initialised", C.c_int32), ("screen_prezeroed", C.c_int32), ("binning_capacity", C.c_int64)]
+                ("binning_initialised", C.c_int32), ("screen_prezeroed", C.c_int32), ("binning_capacity", C.c_int64),
+                ("chunk_key_end", C.c_uint32 * MAX_CHUNKS), ("chunks_sorted", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class DebugViews(C.Structure):
@@ -61,7 +62,7 @@ class DebugViews(C.Structure):
 
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess",
-           "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
+           "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_backward_geom_rows", "gsr_frame_arrays", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows", "gsr_loss_l1_backward",
            "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_adam_step_split", "gsr_densify_stats",
            "gsr_activations_forward", "gsr_activations_backward")
@@ -182,6 +183,27 @@ def backward_geom(desc, cam: Camera, g: Gaussians, radii, geom_ws, screen_grads,
     _check(load().gsr_backward_geom(C.byref(desc), C.byref(cam), C.byref(g), _ptr(radii), _ptr(geom_ws),
                                     _ptr(screen_grads), C.c_int32(g0), C.c_int32(g1), C.c_int32(binned_ranks), C.byref(grads),
                                     _stream(device)), "gsr_backward_geom")
+
+
+def backward_geom_rows(desc, cam: Camera, g: Gaussians, radii, geom_ws, screen_grads, rows, grads: Grads, device):
+    """Sparse geometry backward over the Gaussians listed in `rows` (int32 device tensor)."""
+    _check(load().gsr_backward_geom_rows(C.byref(desc), C.byref(cam), C.byref(g), _ptr(radii), _ptr(geom_ws), _ptr(screen_grads),
+                                         _ptr(rows), C.c_int32(rows.numel()), C.byref(grads), _stream(device)), "gsr_backward_geom_rows")
+
+
+_frame_offsets = {}
+
+
+def frame_arrays(desc, geom_ws):
+    """(depth_keys, depth_order): int32 views [P] into the geometry workspace (keys: bits of the view depth, -1 = invisible)."""
+    P = desc.P
+    offs = _frame_offsets.get(P)
+    if offs is None:
+        k, o = C.c_void_p(), C.c_void_p()
+        _check(load().gsr_frame_arrays(C.byref(desc), _ptr(geom_ws), C.byref(k), C.byref(o)), "gsr_frame_arrays")
+        base = geom_ws.data_ptr()
+        offs = _frame_offsets[P] = (int(k.value) - base, int(o.value) - base)
+    return tuple(geom_ws[o:o + 4 * P].view(torch.int32) for o in offs)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix, present):

@@ -84,9 +84,12 @@ class NativeBackend:
         from . import rasterize_backward_screen
         return rasterize_backward_screen(frame, grad_color)
 
-    def backward_geom(self, frame, screen, needs, g0, g1, binned_ranks=-1):
+    def backward_geom(self, frame, screen, needs, g0, g1, rows=None):
+        """rows: Gaussian indices (device tensor) that may carry a screen gradient, None = any (dense)."""
         from . import rasterize_backward_geom
-        return rasterize_backward_geom(frame, screen, needs, g0, g1, binned_ranks=binned_ranks)
+        if rows is None:
+            return rasterize_backward_geom(frame, screen, needs, g0, g1, binned_ranks=-1)
+        return rasterize_backward_geom(frame, screen, needs, g0, g1, rows=rows.to(torch.int32))
 
     def prepare_backward(self, frame, needs):
         """Early zero fill of the backward's outputs (gsr_backward_prepare) while the stream waits for the all-gather."""
@@ -102,12 +105,18 @@ class NativeBackend:
         return (rng[..., 1] - rng[..., 0]).sum(0).view(Gy, Gx).sum(1).to(torch.float32)
 
     def binned_prefix(self, frame):
-        """(depth_order[P] as a device tensor, number of leading depth ranks that may own gradient rows)."""
+        """(keys, key_end, n): keys [P] = a sort key per Gaussian that is the SAME on every rank (bits of the view depth;
+        negative = not visible); this rank binned exactly the n Gaussians with 0 <= key <= key_end, so only they can own
+        gradient rows here.  Chunks are selected by depth key, so 'everything up to the largest key_end of any rank' is
+        the same set on every rank."""
         from . import _native as N
         plan = frame.plan
-        n = int(plan.chunk_rank_begin[plan.chunks_run]) if plan.num_rendered > 0 and plan.chunks_run > 0 else 0
-        v = N.debug_views(frame.desc, frame.geom_ws, None, None, plan)
-        return v["depth_order"], n
+        run = int(plan.chunks_run) if plan.num_rendered > 0 else 0
+        keys, _ = N.frame_arrays(frame.desc, frame.geom_ws)
+        if run <= 0:
+            return keys, -1, 0
+        # (the last chunk's end is 'everything': clamp to the largest key an int32 view can hold)
+        return keys, min(int(plan.chunk_key_end[run - 1]), 0x7FFFFFFF), int(plan.chunk_rank_begin[run])
 
 
 class _Comm:
@@ -133,17 +142,21 @@ class _Comm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def max_int(self, value: int, device) -> int:
-        t = torch.tensor([int(value)], dtype=torch.int64, device="cpu" if self.gloo else device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
-        return int(t.item())
+    def widest_prefix(self, key_end: int, n: int, device):
+        """(max over ranks of key_end, the n of a rank that holds it): one small all-gather (the path without a forward
+        piggyback)."""
+        t = torch.tensor([[int(key_end), int(n)]], dtype=torch.int64, device="cpu" if self.gloo else device)
+        allr = self.all_gather(t)
+        return max((int(k), int(m)) for k, m in allr.tolist())
 
     def read_halves_later(self, halves: torch.Tensor):
-        """halves [world, 2] = (n >> 16, n & 0xFFFF) per rank as floats: one copy to pinned memory + an event now; the
-        returned callable waits for that event only and returns max over ranks of n.  (A blocking .item() in the
-        backward would drain the whole forward + loss from the stream.)"""
+        """halves [world, 4] = (key_end + 1 >> 16, key_end + 1 & 0xFFFF, n >> 16, n & 0xFFFF) per rank as floats: one copy to
+        pinned memory + an event now; the returned callable waits for that event only and returns (largest key_end over
+        the ranks, the n of a rank that holds it).  (A blocking .item() in the backward would drain the whole forward +
+        loss from the stream.)"""
+        pick = lambda rows: max((int(a) * 65536 + int(b) - 1, int(c) * 65536 + int(d)) for a, b, c, d in rows)
         if halves.device.type != "cuda":
-            v = int((halves[:, 0].to(torch.int64) * 65536 + halves[:, 1].to(torch.int64)).max().item())
+            v = pick(halves.tolist())
             return lambda: v
         host = torch.empty(halves.shape, dtype=halves.dtype).pin_memory()
         host.copy_(halves, non_blocking=True)
@@ -152,7 +165,7 @@ class _Comm:
 
         def read():
             ev.synchronize()
-            return max(int(h) * 65536 + int(l) for h, l in host.tolist())
+            return pick(host.tolist())
         return read
 
     def reduce_scatter_sum(self, full: torch.Tensor) -> torch.Tensor:
@@ -194,25 +207,25 @@ class _ShardedRasterize(torch.autograd.Function):
             color, radii, frame = backend.forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                                   rs, slab, full)
         y0, y1 = min(ty0 * 16, H), min(ty1 * 16, H)
-        # all-gather payload per rank: its slab padded to rows_max rows, plus two trailing words that carry the length of
-        # its binned depth prefix (as 16-bit halves, exact in any float type) so that the MAX over ranks needs no
-        # collective of its own
+        # all-gather payload per rank: its slab padded to rows_max rows, plus four trailing words that carry the depth key up to
+        # which it binned and how many Gaussians that is (as 16-bit halves, exact in any float type) so that the widest
+        # prefix over the ranks needs no collective of its own
         n_words = 3 * rows_max * W
-        mine = torch.empty(1, n_words + 2 + (Gy if balance else 0), dtype=full.dtype, device=full.device)
+        mine = torch.empty(1, n_words + 4 + (Gy if balance else 0), dtype=full.dtype, device=full.device)
         if y1 > y0:
             mine[0, :n_words].view(3, rows_max, W)[:, :y1 - y0] = full[:, y0:y1]
         needs = tuple(ctx.needs_input_grad[:8]) + ((bool(ctx.needs_input_grad[10]),) if raw else ())
         ctx.needs = needs
         from . import caller_grad_enabled          # Function.forward itself runs with grad mode off
         want_prefix = shard.backward_mode == "allreduce_screen" and any(needs) and caller_grad_enabled()
-        order, n_mine = backend.binned_prefix(frame) if want_prefix else (None, 0)
-        mine[0, n_words].fill_(float(int(n_mine) >> 16))
-        mine[0, n_words + 1].fill_(float(int(n_mine) & 0xFFFF))
+        keys, k_mine, n_mine = backend.binned_prefix(frame) if want_prefix else (None, -1, 0)
+        for j, v in enumerate(((int(k_mine) + 1) >> 16, (int(k_mine) + 1) & 0xFFFF, int(n_mine) >> 16, int(n_mine) & 0xFFFF)):
+            mine[0, n_words + j].fill_(float(v))
         if balance:          # this rank's per-tile-row work rides along; the sum over ranks is next frames' slab weights
-            mine[0, n_words + 2:] = backend.row_work(frame, (W + 15) // 16, Gy).to(mine.dtype)
-        gathered = comm.all_gather(mine)                        # [world, 3 * rows_max * W + 2 (+ Gy)]
+            mine[0, n_words + 4:] = backend.row_work(frame, (W + 15) // 16, Gy).to(mine.dtype)
+        gathered = comm.all_gather(mine)                        # [world, 3 * rows_max * W + 4 (+ Gy)]
         if balance:
-            shard.set_row_work(gathered[:, n_words + 2:].sum(0))
+            shard.set_row_work(gathered[:, n_words + 4:].sum(0))
         for r, (a, b) in enumerate(slabs):
             a_px, b_px = min(a * 16, H), min(b * 16, H)
             if b_px > a_px and r != comm.rank:
@@ -220,9 +233,9 @@ class _ShardedRasterize(torch.autograd.Function):
         ctx.frame, ctx.shard, ctx.rs = frame, shard, rs
         ctx.n_max = None
         if want_prefix:
-            # longest binned depth prefix over the ranks: sizes the backward's gradient exchange; on its way to pinned
-            # host memory now, so that the backward finds it without a stream drain
-            ctx.n_max = (order, comm.read_halves_later(gathered[:, n_words:n_words + 2]) if order is not None else None)
+            # widest binned depth prefix over the ranks: selects and sizes the backward's gradient exchange; on its way to
+            # pinned host memory now, so that the backward finds it without a stream drain
+            ctx.n_max = (keys, comm.read_halves_later(gathered[:, n_words:n_words + 4]) if keys is not None else None)
             hook = getattr(backend, "prepare_backward", None)       # the native provider zero-fills the backward's outputs now
             if hook is not None:
                 hook(frame, needs)
@@ -239,22 +252,24 @@ class _ShardedRasterize(torch.autograd.Function):
         # (1) my slab's contribution to every Gaussian's screen-space gradient
         partial = backend.backward_screen(frame, grad_color)                       # [P, 12]
         if shard.backward_mode == "allreduce_screen":
-            # (2) sum over slabs; only the binned prefix of the depth order can be non-zero on any rank
+            # (2) sum over slabs; only Gaussians some rank binned can be non-zero: those whose key is <= the largest chunk end
+            # any rank reached (the same set, in index order, on every rank: keys do not depend on the slab)
             if ctx.n_max is not None:
-                order, read = ctx.n_max
-                n_max = read() if read is not None else P
+                keys, read = ctx.n_max
+                k_max, n_max = read() if read is not None else (-1, P)
             else:
-                order, n_mine = backend.binned_prefix(frame)
-                n_max = comm.max_int(n_mine, partial.device)
-            if order is None or n_max >= P:
+                keys, k_mine, n_mine = backend.binned_prefix(frame)
+                k_max, n_max = comm.widest_prefix(k_mine, n_mine, partial.device) if keys is not None else (-1, P)
+            idx = None
+            if keys is None or n_max >= P:
                 screen = comm.all_reduce_sum(partial.contiguous())
             else:
-                screen = partial                                    # rows outside the prefix are zero on every rank
+                screen = partial                                    # rows outside the set are zero on every rank
+                idx = torch.nonzero_static((keys >= 0) & (keys <= k_max), size=n_max).view(-1)      # n_max is exact: no host sync
                 if n_max > 0:
-                    idx = order[:n_max] if order.dtype in (torch.int32, torch.int64) else order[:n_max].long()
                     screen[idx] = comm.all_reduce_sum(partial[idx].contiguous())       # in place: `partial` is not used again
             # (3) every rank runs the whole geometry backward: full parameter gradients, no further collective
-            out = list(backend.backward_geom(frame, screen, needs, 0, P, n_max if order is not None else -1))
+            out = list(backend.backward_geom(frame, screen, needs, 0, P, idx))
         else:
             g0, g1, slen = gaussian_shard(P, comm.world, comm.rank)
             padded = torch.zeros(comm.world * slen, SCREEN_STRIDE, dtype=partial.dtype, device=partial.device)

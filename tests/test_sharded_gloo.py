@@ -42,15 +42,16 @@ class OracleBackend:
         return out.to(grad_color.dtype)
 
     def binned_prefix(self, fr):
-        # the oracle bins everything: no usable prefix -> dense exchange (exercised), or a fake prefix in depth order
+        # the oracle bins everything: no usable prefix -> dense exchange (exercised), or the keyed form: keys = bits of the
+        # fp32 view depth (negative = invisible), this rank "binned" everything up to the largest key
         if not getattr(self, "use_prefix", False):
-            return None, fr.P
-        vis = np.nonzero(fr.radii > 0)[0]
-        order = vis[np.lexsort((vis, fr.depth[vis]))]
-        rest = np.setdiff1d(np.arange(fr.P), order)
-        return torch.from_numpy(np.concatenate([order, rest])), int(order.size)
+            return None, -1, fr.P
+        vis = fr.radii > 0
+        keys = np.where(vis, fr.depth.astype(np.float32).view(np.int32), -1).astype(np.int64)
+        cut = int(keys[vis].max()) if vis.any() else -1
+        return torch.from_numpy(keys), cut, int(((keys >= 0) & (keys <= cut)).sum())
 
-    def backward_geom(self, fr, screen, needs, g0, g1, binned_ranks=-1):
+    def backward_geom(self, fr, screen, needs, g0, g1, rows=None):
         g = fr.backward_geom(screen[:, :9].double().numpy(), g0, g1)
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(screen.dtype)
         return (t(g["means3D"]), t(g["means2D"]), t(g["shs"]) if fr.M else None,
