@@ -576,7 +576,7 @@ int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_
     int bits = bits_of(key_hi > base ? key_hi - base : 0u);
     if (bits < 1) bits = 1;
     if (n <= kSmallSortMax) {
-        static const int force_radix = getenv("GSR_SORT_FORCE_RADIX") ? 1 : 0;        // test hook: the fallback path of the LDS sort
+        const int force_radix = getenv("GSR_SORT_FORCE_RADIX") ? 1 : 0;               // test hook: the fallback path of the LDS sort
         ProfileScope prof("chunk_sort", s);
         hipLaunchKernelGGL(k_chunk_sort_small, dim3(1), dim3(kSmallThreads), 0, s, n, (uint32_t)r0, bits, force_radix, ws.sort_keys[1],
                            ws.sort_vals[1], ws.order, ws.offs_full);

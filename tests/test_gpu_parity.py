@@ -524,6 +524,33 @@ def test_backward_is_bitwise_deterministic():
         assert np.array_equal(g1[k], g2[k]), k
 
 
+def test_chunk_sort_paths_agree_and_equal_depths_keep_index_order():
+    """The depth order is built per chunk (csrc/gsr_select.hip).  (a) The one-block LDS sort's two paths — bucket + rank sort,
+    and the 4-bit radix passes it falls back to when keys crowd into one bucket — give bitwise the same frame and gradients.
+    (b) Gaussians with bit-identical depth (4000 of them on one plane facing the camera: every one of them lands in the same
+    bucket, so the fallback runs on its own) blend in index order, as the reference's stable sort has it: parity with the oracle
+    at the strict bound."""
+    c = dict(P=5000, W=256, H=192, D=3, seed=109)
+    kw = _fixture_kwargs(c)
+    gimg = S.make_grad_image(256, 192, 9).numpy()
+    c1, r1, g1 = _run_gpu(kw, gimg)
+    os.environ["GSR_SORT_FORCE_RADIX"] = "1"
+    try:
+        c2, r2, g2 = _run_gpu(kw, gimg)
+    finally:
+        del os.environ["GSR_SORT_FORCE_RADIX"]
+    assert np.array_equal(c1, c2) and np.array_equal(r1, r2)
+    for k in g1:
+        assert np.array_equal(g1[k], g2[k]), k
+    kw = _fixture_kwargs(dict(P=6000, W=256, H=192, D=1, seed=131))
+    kw["means3D"] = kw["means3D"].copy()
+    kw["means3D"][:4000, 2] = 1.5                              # S.make_camera looks down +z from the origin: view depth = z
+    fr64 = oracle.rasterize(dtype=np.float64, **kw)
+    assert np.unique(fr64.depth[:4000][fr64.radii[:4000] > 0].astype(np.float32)).size == 1
+    *_, live = _forward_backward_strict(kw, fr64, gimg, label="equal depths")
+    assert live > 100
+
+
 def test_slab_renders_tile_the_image_and_gradients_sum():
     """Tile-row slabs (multi-GPU sharding) on one device: slabs reproduce the full render
     bit-for-bit, and slab screen-space gradients sum to the full ones."""
