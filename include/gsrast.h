@@ -73,7 +73,9 @@ typedef struct gsr_frame_plan {
                                                      -1 when the last chunk ran (its count is not read back)  */
     int32_t binning_initialised;                  /* gsr_forward_preprocess was given the image workspace and has
                                                      already reset the tile ranges / open flags in it        */
-    int32_t screen_prezeroed;                     /* set by gsr_backward_prepare: screen_grads is already all zero   */
+    int32_t screen_prezeroed;                     /* 1 (set by gsr_backward_prepare): screen_grads is already all zero; 2 (set by
+                                                     the caller): only the rows of the binned depth prefix will be read (by the
+                                                     sparse gsr_backward_geom of this frame) - no clearing at all            */
     int64_t binning_capacity;                     /* IN to gsr_forward_render (and the backward): instances the binning
                                                      workspace was sized for (gsr_binning_size of that number); 0 = R   */
     uint32_t chunk_key_end[GSR_MAX_CHUNKS];       /* chunk c = visible Gaussians whose depth bits lie in (key_end[c-1], key_end[c]]:

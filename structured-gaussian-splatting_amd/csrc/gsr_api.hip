@@ -402,7 +402,7 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     const int n_ranks = (plan->num_rendered > 0 && plan->chunks_run > 0) ? plan->chunk_rank_begin[plan->chunks_run] : 0;
     long long rows_upper = 0;
     for (int c = 0; c < plan->chunks_run && c < GSR_MAX_CHUNKS; ++c) rows_upper += plan->chunk_instances_max[c];
-    if ((rc = launch_reduce_rows(f, n_ranks, rows_upper, gw, bw, screen_grads, plan->screen_prezeroed != 0, dbg, s))) return rc;
+    if ((rc = launch_reduce_rows(f, n_ranks, rows_upper, gw, bw, screen_grads, plan->screen_prezeroed, dbg, s))) return rc;
     return GSR_OK;
 }
 

@@ -181,7 +181,7 @@ int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, in
                       const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s);
 int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s);
 int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
-                       float *screen_grads, bool prezeroed, bool debug, hipStream_t s);
+                       float *screen_grads, int prezeroed, bool debug, hipStream_t s);
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
                     const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s,
                     const uint32_t *rows = nullptr);

@@ -544,7 +544,8 @@ template <int kRedGroup>
 __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const uint32_t *__restrict__ order,
                                                            const uint32_t *__restrict__ cnt_open,
                                                            const uint32_t *__restrict__ row_begin,
-                                                           const float4 *__restrict__ grad_rows, float4 *__restrict__ screen)
+                                                           const float4 *__restrict__ grad_rows, float4 *__restrict__ screen,
+                                                           int write_empty)
 {
     const int sub = threadIdx.x & (kRedGroup - 1);
     const int r = (blockIdx.x * kRedBlock + threadIdx.x) / kRedGroup;
@@ -568,18 +569,21 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const ui
         a1.x += __shfl_xor(a1.x, off); a1.y += __shfl_xor(a1.y, off); a1.z += __shfl_xor(a1.z, off); a1.w += __shfl_xor(a1.w, off);
         a8 += __shfl_xor(a8, off);
     }
-    if (live && cnt && sub < 3) {
+    if (live && (cnt || write_empty) && sub < 3) {
         const uint32_t g = order[r];
         screen[3 * (size_t)g + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : make_float4(a8, 0.f, 0.f, 0.f));
     }
 }
 
 int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
-                       float *screen_grads, bool prezeroed, bool debug, hipStream_t s)
+                       float *screen_grads, int prezeroed, bool debug, hipStream_t s)
 {
+    // prezeroed: 0 = clear the whole tensor first; 1 = the caller already has; 2 = only the rows of the binned prefix will ever
+    // be read (the sparse geometry backward of the same frame): every prefix row is written, zeros included, nothing else
     if (f.P == 0) return GSR_OK;
     ProfileScope prof("reduce_rows", s);
-    if (!prezeroed) GSR_HIP_CHECK(hipMemsetAsync(screen_grads, 0, (size_t)f.P * kRowFloats * sizeof(float), s));
+    if (prezeroed == 0) GSR_HIP_CHECK(hipMemsetAsync(screen_grads, 0, (size_t)f.P * kRowFloats * sizeof(float), s));
+    const int write_empty = prezeroed == 2 ? 1 : 0;
     if (n_ranks > 0) {
         // lanes per Gaussian: a whole wave when the processed Gaussians own many rows each (depth-complex scenes:
         // a few thousand screen-filling splats), eight otherwise
@@ -588,10 +592,10 @@ int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const
         const dim3 grid((unsigned)((threads + kRedBlock - 1) / kRedBlock));
         if (wide)
             hipLaunchKernelGGL(k_reduce_rows<64>, grid, dim3(kRedBlock), 0, s, n_ranks, gw.order, gw.cnt_open, gw.row_begin,
-                               reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads));
+                               reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
         else
             hipLaunchKernelGGL(k_reduce_rows<8>, grid, dim3(kRedBlock), 0, s, n_ranks, gw.order, gw.cnt_open, gw.row_begin,
-                               reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads));
+                               reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
     }
     GSR_LAUNCH_CHECK("reduce_rows", debug, s);
     return GSR_OK;

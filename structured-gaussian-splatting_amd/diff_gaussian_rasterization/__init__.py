@@ -230,7 +230,7 @@ def _alloc_grads(fr: "_Frame", needs, alloc):
     return t, grads
 
 
-def prepare_backward(fr: "_Frame", needs) -> None:
+def prepare_backward(fr: "_Frame", needs, screen_prefix_only: bool = False) -> None:
     """Called right after the forward when a backward will follow: the stream is idle while the host walks back
     through the caller's code to the loss, so the backward's zero fills (screen-space gradients + the parameter
     gradients of the sparse geometry backward, ~280 MB at 1e6 Gaussians) are enqueued NOW, in one launch, into the
@@ -251,7 +251,11 @@ def prepare_backward(fr: "_Frame", needs) -> None:
     if fr.pre["grads"].prezeroed:
         return
     with torch.cuda.device(fr.device):
-        N.backward_prepare(fr.desc, fr.gauss, plan, fr.pre["screen"], fr.pre["grads"], fr.device)
+        # screen_prefix_only: the screen-space gradients go straight into this frame's sparse geometry backward, which reads
+        # the rows of the binned prefix only (the autograd path): that tensor needs no clearing at all
+        N.backward_prepare(fr.desc, fr.gauss, plan, None if screen_prefix_only else fr.pre["screen"], fr.pre["grads"], fr.device)
+        if screen_prefix_only:
+            plan.screen_prezeroed = 2
 
 
 def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int = 0, g1: Optional[int] = None,
@@ -342,7 +346,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise
         else:
             color, radii, frame = rasterize_forward(*args, rs, prepare_needs=tuple(ctx.needs_input_grad[:8]))
-            prepare_backward(frame, tuple(ctx.needs_input_grad[:8]))       # frames the early path did not take (single chunk)
+            prepare_backward(frame, tuple(ctx.needs_input_grad[:8]), screen_prefix_only=True)
         _stash_frame(ctx, frame)
         ctx.raster_settings = rs
         ctx.shapes = (means2D.shape, opacities.shape)
@@ -393,7 +397,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                                                 sh_rest=features_rest, raw=True, prepare_needs=None if rs.debug else needs)
         if rs.debug:
             torch.cuda.synchronize(xyz.device)
-        prepare_backward(frame, needs)
+        prepare_backward(frame, needs, screen_prefix_only=True)
         _stash_frame(ctx, frame)
         ctx.shapes = (means2D.shape, opacity_logits.shape)
         ctx.mark_non_differentiable(radii)
