@@ -83,8 +83,10 @@ __device__ __forceinline__ void first_crossing(const unsigned long long *cum_t, 
 
 // ---- 1b. level-1 scan: V, R, the bin of every boundary; the first
 // kSelRefine boundaries get refined at level 2
+// (every block of the level-2 histogram runs this on its own — 40 KB of table out of L2 and a scan, cheaper than a one-block
+// launch in between; block 0 stores the result for the plan step, the others only use sh_first)
 __device__ void sel_plan1(unsigned long long first_mass, SelState *st, uint32_t *cum_n, unsigned long long *cum_t, unsigned long long *cum_m,
-                          Triple *sh_wave, uint32_t *sh_first /* [GSR_MAX_CHUNKS] */)
+                          Triple *sh_wave, uint32_t *sh_first /* [GSR_MAX_CHUNKS] */, bool write)
 {
     if (threadIdx.x < GSR_MAX_CHUNKS) sh_first[threadIdx.x] = (uint32_t)kSelBins;
     scan_table(st->t1, Triple{0u, 0ull, 0ull}, cum_n, cum_t, cum_m, sh_wave);
@@ -96,6 +98,7 @@ __device__ void sel_plan1(unsigned long long first_mass, SelState *st, uint32_t 
     }
     __syncthreads();
     const int c = threadIdx.x;
+    if (!write) return;
     if (c == 0) { st->V = V; st->R = R; }
     if (c < GSR_MAX_CHUNKS - 1) {
         const uint32_t b = sh_first[c];                         // kSelBins: no boundary, the chunk takes everything left
@@ -112,8 +115,11 @@ __device__ void sel_plan1(unsigned long long first_mass, SelState *st, uint32_t 
 
 // ---- 1d. level-2 scan of the refined boundaries, then the plan itself:
 // key thresholds, rank boundaries, instance bounds
-__device__ void sel_plan2(unsigned long long first_mass, SelState *st, Ctrl *ctrl, uint32_t *cum_n, unsigned long long *cum_t,
-                          unsigned long long *cum_m, Triple *sh_wave, uint32_t *sh_small /* [4 * GSR_MAX_CHUNKS] */)
+// (every block of the partition's count pass runs this on its own; block 0 stores the plan, all of them leave the chunk
+// count and the key thresholds in out_n / out_ends)
+__device__ void sel_plan2(unsigned long long first_mass, const SelState *st, Ctrl *ctrl, uint32_t *cum_n, unsigned long long *cum_t,
+                          unsigned long long *cum_m, Triple *sh_wave, uint32_t *sh_small /* [4 * GSR_MAX_CHUNKS] */, bool write,
+                          uint32_t *out_n, uint32_t *out_ends /* [GSR_MAX_CHUNKS] */)
 {
     uint32_t *sh_sub = sh_small, *sh_key = sh_small + GSR_MAX_CHUNKS, *sh_cnt = sh_small + 2 * GSR_MAX_CHUNKS;
     __shared__ unsigned long long sh_tiles[GSR_MAX_CHUNKS];
@@ -132,10 +138,11 @@ __device__ void sel_plan2(unsigned long long first_mass, SelState *st, Ctrl *ctr
         }
         __syncthreads();
     }
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0) return;                               // (the caller's next barrier publishes out_n / out_ends)
     // the plan: chunks in depth order; an empty one (two boundaries inside one sub-bin) is merged into its successor
     const uint32_t V = st->V;
     uint32_t n = 0, begin = 0;
+    uint32_t p_key[GSR_MAX_CHUNKS], p_cnt[GSR_MAX_CHUNKS], p_full[GSR_MAX_CHUNKS];
     unsigned long long begin_tiles = 0;
     for (int k = 0; k < GSR_MAX_CHUNKS && begin < V; ++k) {
         uint32_t key = 0xFFFFFFFEu, cnt = V;
@@ -148,15 +155,17 @@ __device__ void sel_plan2(unsigned long long first_mass, SelState *st, Ctrl *ctr
             }
         }
         if (cnt <= begin) continue;
-        ctrl->key_end[n] = key;
-        ctrl->bnd[n + 1] = cnt;
         const unsigned long long full = tiles - begin_tiles;
-        ctrl->chunk_full[n] = full > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)full;
+        p_key[n] = key; p_cnt[n] = cnt; p_full[n] = full > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)full;
         begin = cnt; begin_tiles = tiles;
         ++n;
         if (cnt >= V) break;
     }
-    for (uint32_t k = n; k < GSR_MAX_CHUNKS; ++k) { ctrl->key_end[k] = 0xFFFFFFFEu; ctrl->bnd[k + 1] = V; ctrl->chunk_full[k] = 0; }
+    for (uint32_t k = n; k < GSR_MAX_CHUNKS; ++k) { p_key[k] = 0xFFFFFFFEu; p_cnt[k] = V; p_full[k] = 0; }
+    *out_n = n;
+    for (int k = 0; k < GSR_MAX_CHUNKS; ++k) out_ends[k] = p_key[k];
+    if (!write) return;
+    for (int k = 0; k < GSR_MAX_CHUNKS; ++k) { ctrl->key_end[k] = p_key[k]; ctrl->bnd[k + 1] = p_cnt[k]; ctrl->chunk_full[k] = p_full[k]; }
     for (int k = 0; k < GSR_MAX_CHUNKS; ++k) { ctrl->chunk_R[k] = 0; ctrl->chunk_base[k + 1] = 0; }
     ctrl->bnd[0] = 0; ctrl->chunk_base[0] = 0;
     ctrl->V = V;
@@ -169,17 +178,22 @@ __device__ void sel_plan2(unsigned long long first_mass, SelState *st, Ctrl *ctr
 // ---- 1a/1c. histograms (LEVEL 1: all visible Gaussians; LEVEL 2: those inside the bins picked by level 1's plan)
 template <int LEVEL>
 __global__ __launch_bounds__(kSelThreads) void k_sel_hist(int P, const uint32_t *__restrict__ keys, const uint2 *__restrict__ tiles_mass,
-                                                          SelState *st)
+                                                          unsigned long long first_mass, SelState *st)
 {
     constexpr int NT = LEVEL == 1 ? 1 : kSelRefine;
     __shared__ uint32_t sh_cnt[NT][kSelBins];
     __shared__ unsigned long long sh_tiles[NT][kSelBins], sh_mass[NT][kSelBins];
+    __shared__ Triple sh_wave[kSelWaves];
+    __shared__ uint32_t sh_first[GSR_MAX_CHUNKS];
     uint32_t want[NT];
     bool any = true;
     if (LEVEL == 2) {
+        // the level-1 plan step, in every block (the histogram arrays hold its running sums first)
+        sel_plan1(first_mass, st, sh_cnt[0], sh_tiles[0], sh_mass[0], sh_wave, sh_first, blockIdx.x == 0);
         any = false;
 #pragma unroll
-        for (int c = 0; c < NT; ++c) { want[c] = st->bin[c]; any |= want[c] < (uint32_t)kSelBins; }
+        for (int c = 0; c < NT; ++c) { want[c] = sh_first[c]; any |= want[c] < (uint32_t)kSelBins; }
+        __syncthreads();
     }
     if (any) {                                                   // (level 2: some boundary needs refining)
         for (int j = threadIdx.x; j < NT * kSelBins; j += kSelThreads) { (&sh_cnt[0][0])[j] = 0; (&sh_tiles[0][0])[j] = 0; (&sh_mass[0][0])[j] = 0; }
@@ -217,18 +231,6 @@ __global__ __launch_bounds__(kSelThreads) void k_sel_hist(int P, const uint32_t 
     }
 }
 
-// The plan steps are their own one-block launches: letting the histogram's last block run them (ticket + __threadfence) was
-// measured at +55 us per frame — a device-scope release on this multi-XCD part writes the L2 back, once per block.
-__global__ __launch_bounds__(kSelThreads) void k_sel_plan(int level, unsigned long long first_mass, SelState *st, Ctrl *ctrl)
-{
-    __shared__ uint32_t cum_n[kSelBins];
-    __shared__ unsigned long long cum_t[kSelBins], cum_m[kSelBins];
-    __shared__ Triple sh_wave[kSelWaves];
-    __shared__ uint32_t sh_small[4 * GSR_MAX_CHUNKS];
-    if (level == 1) sel_plan1(first_mass, st, cum_n, cum_t, cum_m, sh_wave, sh_small);
-    else sel_plan2(first_mass, st, ctrl, cum_n, cum_t, cum_m, sh_wave, sh_small);
-}
-
 // ---- 2. stable partition of the visible Gaussians by chunk: order[bnd[c] + j] = the j-th (by index) Gaussian of chunk c
 __device__ __forceinline__ int sel_chunk_of(uint32_t key, const uint32_t *ends, int n)
 {
@@ -246,13 +248,21 @@ __device__ __forceinline__ void sel_block_range(int P, int &lo, int &hi)
     hi = l + per < P ? (int)(l + per) : P;
 }
 
-__global__ __launch_bounds__(kSelThreads) void k_part_count(int P, const uint32_t *__restrict__ keys, const Ctrl *__restrict__ ctrl, SelState *st)
+__global__ __launch_bounds__(kSelThreads) void k_part_count(int P, const uint32_t *__restrict__ keys, unsigned long long first_mass, Ctrl *ctrl,
+                                                            SelState *st)
 {
     __shared__ uint32_t sh_cnt[GSR_MAX_CHUNKS];
     __shared__ uint32_t ends[GSR_MAX_CHUNKS];
-    const int n = (int)ctrl->num_chunks;
-    if (threadIdx.x < GSR_MAX_CHUNKS) { sh_cnt[threadIdx.x] = 0; ends[threadIdx.x] = ctrl->key_end[threadIdx.x]; }
+    __shared__ uint32_t cum_n[kSelBins];
+    __shared__ unsigned long long cum_t[kSelBins], cum_m[kSelBins];
+    __shared__ Triple sh_wave[kSelWaves];
+    __shared__ uint32_t sh_small[4 * GSR_MAX_CHUNKS];
+    __shared__ uint32_t sh_n;
+    // the plan step (level-2 scan + chunk table), in every block; block 0 stores it for the scatter pass and the host
+    sel_plan2(first_mass, st, ctrl, cum_n, cum_t, cum_m, sh_wave, sh_small, blockIdx.x == 0, &sh_n, ends);
+    if (threadIdx.x < GSR_MAX_CHUNKS) sh_cnt[threadIdx.x] = 0;
     __syncthreads();
+    const int n = (int)sh_n;
     int lo, hi;
     sel_block_range(P, lo, hi);
     uint32_t mine[GSR_MAX_CHUNKS] = {};
@@ -335,15 +345,13 @@ int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
     if (blocks > kSelBlocks) blocks = kSelBlocks;
     {
         ProfileScope prof("depth_hist", s);
-        hipLaunchKernelGGL(k_sel_hist<1>, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, ws.sel);
-        hipLaunchKernelGGL(k_sel_plan, dim3(1), dim3(kSelThreads), 0, s, 1, first_mass, ws.sel, ws.ctrl);
-        hipLaunchKernelGGL(k_sel_hist<2>, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, ws.sel);
-        hipLaunchKernelGGL(k_sel_plan, dim3(1), dim3(kSelThreads), 0, s, 2, first_mass, ws.sel, ws.ctrl);
+        hipLaunchKernelGGL(k_sel_hist<1>, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, first_mass, ws.sel);
+        hipLaunchKernelGGL(k_sel_hist<2>, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, first_mass, ws.sel);
         GSR_LAUNCH_CHECK("depth_hist", debug, s);
     }
     {
         ProfileScope prof("depth_partition", s);
-        hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.ctrl, ws.sel);
+        hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], first_mass, ws.ctrl, ws.sel);
         hipLaunchKernelGGL(k_part_scatter, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, ws.ctrl, ws.sel, ws.order,
                            ws.sort_keys[1], ws.sort_vals[1]);
         GSR_LAUNCH_CHECK("depth_partition", debug, s);
