@@ -144,12 +144,14 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 // instead of all the visible ones.
 template <int DEG, bool RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors(FrameK f, int r0, int r1, const uint32_t *__restrict__ order,
+                                                             const uint32_t *__restrict__ cnt_open,
                                                              const float *__restrict__ campos, const float *__restrict__ means,
                                                              const float *__restrict__ shs, const float *__restrict__ shs_rest,
                                                              float4 *__restrict__ records, uint8_t *__restrict__ clamped)
 {
     const int r = r0 + blockIdx.x * kGeomBlock + threadIdx.x;
     if (r >= r1) return;
+    if (cnt_open[r] == 0u) return;               // no tile took this Gaussian (a late chunk: most tiles are closed): nobody reads its colour
     const int i = (int)order[r];
     const float cp[3] = {campos[0], campos[1], campos[2]};
     const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
@@ -290,7 +292,7 @@ int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussi
     }
     const int grid = (r1 - r0 + kGeomBlock - 1) / kGeomBlock;
 #define GSR_CC(DEG, RAW)                                                                                             \
-    hipLaunchKernelGGL((k_chunk_colors<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, r0, r1, ws.order, cam.campos,     \
+    hipLaunchKernelGGL((k_chunk_colors<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, r0, r1, ws.order, ws.cnt_open, cam.campos, \
                        g.means3D, g.shs, g.shs_rest, ws.records, ws.clamped)
     if (g.raw) {
         switch (f.D) {
@@ -401,8 +403,13 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
         GaussIn<DEG, RAW> in;
         load_gaussian<DEG, RAW>(i, M, means, scales, rots, covpre, opac, nullptr, nullptr, false, in);      // SH: from the LDS row
         const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
+        // The clamp mask of an SH colour is recomputed from the coefficients (the forward's own function), not read: colours are
+        // evaluated lazily, only for Gaussians some tile of THIS frame took, and a rank of a sharded render back-propagates
+        // Gaussians that only the other ranks binned.
+        unsigned clamp_bits = clamped[i];
+        if (shs && !has_colpre) { float rgb_[3]; sh_color_one<DEG>(f, cp, in.p, my_row, rgb_, clamp_bits); }
         geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, shs ? my_row : nullptr, has_colpre != 0,
-                               clamped[i], sg, g, my_row, sh_wanted);
+                               clamp_bits, sg, g, my_row, sh_wanted);
         if constexpr (RAW) activate_raw_backward(in.act, g);
     }
     if (!in_range) { /* lanes past the end only help with the cooperative SH store below */ }
@@ -482,7 +489,9 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
     const float sg[9] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x};
     GeomGrad g;
     float dsh[3 * (DEG + 1) * (DEG + 1)];          // constant indices only: stays in registers
-    geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh(), has_colpre != 0, clamped[i],
+    unsigned clamp_bits = clamped[i];               // (recomputed for SH colours: see k_geom_bwd)
+    if (shs && !has_colpre) { float rgb_[3]; sh_color_one<DEG>(f, cp, in.p, in.sh(), rgb_, clamp_bits); }
+    geom_backward_one<DEG>(f, V, PV, cp, in.p, in.sc, in.q, (!RAW && covpre) ? in.cv : nullptr, in.sh(), has_colpre != 0, clamp_bits,
                            sg, g, dsh, shs != nullptr);
     if constexpr (RAW) activate_raw_backward(in.act, g);
     if (out.means3D) { out.means3D[3 * i] = g.dmean[0]; out.means3D[3 * i + 1] = g.dmean[1]; out.means3D[3 * i + 2] = g.dmean[2]; }
