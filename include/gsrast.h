@@ -149,6 +149,19 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
 int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws,
                        void *binning_ws, void *image_ws, gsr_frame_plan *plan_host, float *out_color, void *stream);
 
+/* Both stages in ONE call, for callers that bring a binning workspace sized from a guess (the last frame of the same shape):
+ * gsr_forward_preprocess, then — without going back to the caller, whose own code between the two calls (an interpreter, a
+ * framework's dispatcher) costs tens of microseconds of idle stream right after the plan readback — gsr_forward_render into
+ * `binning_ws` if its `binning_capacity` instances cover what gsr_binning_first_chunk_capacity asks for.  If they do not:
+ * GSR_ERR_WORKSPACE with the plan filled in and nothing of stage 2 enqueued; allocate and call gsr_forward_render.
+ * early_fill (optional): the backward's outputs, as for gsr_backward_prepare (grads->..., any NULL tensor is skipped; the
+ * screen-space tensor is not part of it: see gsr_frame_plan.screen_prezeroed = 2).  When the frame ends sparse
+ * (chunk_rank_begin[chunks_run] * 4 < P) their zero fill is enqueued here, right after the last readback of stage 2, instead of
+ * tens of microseconds later from the caller: early_fill->prezeroed is set and gsr_backward_geom skips its own fill. */
+int gsr_forward(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws, void *image_ws,
+                int32_t *radii, gsr_frame_plan *plan_host, void *binning_ws, int64_t binning_capacity, float *out_color,
+                gsr_grads *early_fill, void *stream);
+
 /* Size of the backward-only scratch: one 48-byte gradient row per instance the forward EMITTED
  * (plan_host->instances_emitted, a few per cent of num_rendered; the emission bound of the chunks that ran
  * when the forward went through its last chunk), so it is allocated when the backward runs and freed right

@@ -344,6 +344,31 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
     return GSR_OK;
 }
 
+int gsr_forward(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws, void *image_ws, int32_t *radii,
+                gsr_frame_plan *plan, void *binning_ws, int64_t binning_capacity, float *out_color, gsr_grads *early_fill, void *stream)
+{
+    int rc = gsr_forward_preprocess(desc, cam, g, geom_ws, image_ws, radii, plan, stream);
+    if (rc) return rc;
+    int64_t need = 0;
+    if ((rc = gsr_binning_first_chunk_capacity(plan, &need))) return rc;
+    if (plan->num_rendered > 0 && (!binning_ws || binning_capacity < need)) {
+        set_error("gsr_forward: the binning workspace holds %lld instances, the first depth chunk may need %lld: allocate and call "
+                  "gsr_forward_render", (long long)binning_capacity, (long long)need);
+        return GSR_ERR_WORKSPACE;
+    }
+    plan->binning_capacity = binning_capacity < plan->num_rendered ? binning_capacity : plan->num_rendered;
+    if (plan->binning_capacity <= 0) plan->binning_capacity = 0;
+    if ((rc = gsr_forward_render(desc, cam, g, geom_ws, binning_ws, image_ws, plan, out_color, stream))) return rc;
+    if (early_fill && !early_fill->prezeroed && desc->P > 0 && plan->num_rendered > 0 && plan->chunks_run > 0 &&
+        (long long)plan->chunk_rank_begin[plan->chunks_run] * 4 < (long long)desc->P) {
+        const FrameK f = make_frame(*desc);
+        ProfileScope prof("zero_outputs", (hipStream_t)stream);
+        if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream))) return rc;
+        early_fill->prezeroed = 1;
+    }
+    return GSR_OK;
+}
+
 int gsr_backward_rows_size(const gsr_frame_desc *desc, const gsr_frame_plan *plan, size_t *rows_bytes)
 {
     int rc = validate(desc);

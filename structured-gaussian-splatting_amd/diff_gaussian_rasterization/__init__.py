@@ -163,7 +163,16 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
         if prepare_needs is not None and P > 0 and any(prepare_needs) and caller_grad_enabled():
             needs = tuple(bool(x) for x in prepare_needs)
             early = (needs,) + _alloc_grads(fr, needs, torch.empty) + (torch.empty(P, N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=device),)
-        fr.plan = plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device, image_ws=fr.image_ws)
+        # With a workspace guessed from the last frame of this shape both stages run in ONE native call (gsr_forward): the
+        # stream is idle from the plan readback until stage 2's first launch, and a trip through the interpreter in between
+        # doubles that gap.  The call also enqueues the backward's zero fill itself, right after stage 2's last readback.
+        done = False
+        if binning is not None:
+            plan, done = N.forward_both(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.image_ws, fr.radii, binning, guess, color, device,
+                                        early_fill=early[2] if early is not None else None)
+        else:
+            plan = N.forward_preprocess(fr.desc, fr.cam, fr.gauss, fr.geom_ws, fr.radii, device, image_ws=fr.image_ws)
+        fr.plan = plan
         if early is not None:          # handed to the backward; prepare_backward() zero-fills them on sparse frames
             needs, tensors, grads, screen = early
             fr.pre = {"needs": needs, "tensors": tensors, "grads": grads, "screen": screen}
@@ -173,10 +182,16 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
         # workspace for R; frames of that shape then start with R.  (Plain arithmetic here, no library calls: the stream is
         # idle between the plan readback and the first launch of stage 2.)
         R = int(plan.num_rendered)
-        first = int(plan.chunk_instances_max[0])
-        capacity = min(first + first // 4 + (1 << 20), R) if plan.num_chunks > 1 else R        # = gsr_binning_first_chunk_capacity
-        capacity = max(capacity, min(guess, R))
-        while True:
+        if done:
+            capacity = int(plan.binning_capacity) if plan.binning_capacity > 0 else guess
+            fr.binning_ws = binning
+        else:
+            first = int(plan.chunk_instances_max[0])
+            capacity = min(first + first // 4 + (1 << 20), R) if plan.num_chunks > 1 else R        # = gsr_binning_first_chunk_capacity
+            capacity = max(capacity, min(guess, R))
+            if binning is not None and capacity <= guess:
+                capacity = R                                   # the guessed workspace covered the first chunk, a later one did not fit
+        while not done:
             need = _binning_bytes(capacity)
             if binning is None or binning.numel() < need:
                 binning = _workspace(need, device)
@@ -248,7 +263,9 @@ def prepare_backward(fr: "_Frame", needs, screen_prefix_only: bool = False) -> N
         tensors, grads = _alloc_grads(fr, needs, torch.empty)
         fr.pre = {"needs": needs, "tensors": tensors, "grads": grads,
                   "screen": torch.empty(P, N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=fr.device)}
-    if fr.pre["grads"].prezeroed:
+    if fr.pre["grads"].prezeroed:              # gsr_forward has already enqueued the fill (parameter gradients only)
+        if screen_prefix_only:
+            plan.screen_prezeroed = 2
         return
     with torch.cuda.device(fr.device):
         # screen_prefix_only: the screen-space gradients go straight into this frame's sparse geometry backward, which reads

@@ -61,7 +61,7 @@ class DebugViews(C.Structure):
                 ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p)]
 
 
-EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess",
+EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess", "gsr_forward",
            "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_backward_geom_rows", "gsr_frame_arrays", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows", "gsr_loss_l1_backward",
            "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_adam_step_split", "gsr_densify_stats",
@@ -153,6 +153,20 @@ def forward_preprocess(desc, cam: Camera, g: Gaussians, geom_ws, radii, device, 
     _check(load().gsr_forward_preprocess(C.byref(desc), C.byref(cam), C.byref(g), _ptr(geom_ws), _ptr(image_ws), _ptr(radii),
                                          C.byref(plan), _stream(device)), "gsr_forward_preprocess")
     return plan
+
+
+def forward_both(desc, cam: Camera, g: Gaussians, geom_ws, image_ws, radii, binning_ws, binning_capacity, out_color, device,
+                 early_fill: Optional[Grads] = None):
+    """gsr_forward: both stages in one call.  Returns (plan, done): done = False when the binning workspace was too small for the
+    first chunk (nothing of stage 2 ran: allocate and call forward_render)."""
+    plan = FramePlan()
+    rc = load().gsr_forward(C.byref(desc), C.byref(cam), C.byref(g), _ptr(geom_ws), _ptr(image_ws), _ptr(radii), C.byref(plan),
+                            _ptr(binning_ws), C.c_int64(int(binning_capacity)), _ptr(out_color),
+                            None if early_fill is None else C.byref(early_fill), _stream(device))
+    if rc == ERR_WORKSPACE:           # the guessed workspace did not do (for the first chunk, or for a later one)
+        return plan, False
+    _check(rc, "gsr_forward")
+    return plan, True
 
 
 def forward_render(desc, cam: Camera, g: Gaussians, geom_ws, binning_ws, image_ws, plan: FramePlan, out_color, device):
