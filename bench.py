@@ -50,8 +50,12 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
     return {
         "preprocess": 52 * P + 67 * V,                      # K1 minus A.6: read 44 + sort key/value 8, write 67 per visible
         "chunk_colors": (12 * K + 12 + 12 + 1) * Vb,        # A.6 for binned Gaussians: SH + mean in, rgb + clamp mask out
-        "depth_sort": 16 * P,                               # minimum: one read + one write of (key, value)
-        "scan_tiles": 12 * P, "chunk_plan": 0, "open_count": 8 * Tn,    # the scan gathers tiles[order[r]] itself
+        # depth order by selection (csrc/gsr_select.hip): two histogram passes over the keys (+ tiles / mass), the stable
+        # partition by chunk (count pass: keys; scatter pass: keys + tiles in, Gaussian / relative key / tiles out per
+        # visible Gaussian), then only the BINNED chunks are sorted: one read + one write of (key, Gaussian) + tiles in,
+        # offsets out per binned Gaussian
+        "depth_hist": 16 * P, "depth_partition": 8 * P + 20 * V, "chunk_sort": 24 * Vb,
+        "scan_tiles": 12 * Vb, "open_count": 8 * Tn,        # chunks beyond the one-block sort: the scan gathers tiles[order[r]] itself
         "count_open": 56 * Vb, "scan_open": 8 * Vb,         # rank -> Gaussian 4 + record 48 + count 4
         "emit": 12 * Re + 56 * Vb,                          # K3: key 4 + slot 4 + Gaussian 4 per instance
         "tile_sort": 16 * Re,                               # K4 minimum: one read + one write of (tile, slot)
@@ -306,7 +310,7 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
         per_step_ms = ms / steps
         per_kernel[k] = dict(ms_per_step=per_step_ms, launches_per_step=n / steps,
                              alg_GBs=(alg.get(k, 0) / 1e9) / (per_step_ms / 1e3) if per_step_ms > 0 else None)
-        keys = {"depth_sort": P, "tile_sort": Re}.get(k)             # SURVEY 8d secondary rate for K4: keys/s
+        keys = {"chunk_sort": Vb, "tile_sort": Re}.get(k)            # SURVEY 8d secondary rate for K4: keys/s
         if keys is not None and per_step_ms > 0:
             per_kernel[k]["Gkeys_per_s"] = keys / 1e9 / (per_step_ms / 1e3)
     raster_ms = sum(ms for ms, _ in prof.values()) / steps
