@@ -24,7 +24,10 @@ NAMES = {
     "void gsr::k_geom_bwd_sparse<": "geom_bwd", "void gsr::k_preprocess<": "preprocess",
     "void gsr::k_reduce_rows<": "reduce_rows", "void gsr::k_loss_fwd<": "loss_fwd", "void gsr::k_loss_bwd<": "loss_bwd",
     "void gsr::k_emit_team<": "emit", "void gsr::k_count_team<": "count_open", "void gsr::k_bin_chunk<false>": "count_open",
-    "void gsr::k_bin_chunk<true>": "emit", "gsr::k_ranges": "ranges",
+    "void gsr::k_bin_chunk<true>": "emit", "gsr::k_ranges": "ranges", "gsr::k_tile_gather": "tile_gather",
+    "gsr::k_tile_ranges": "tile_ranges", "void gsr::k_sel_hist<": "depth_hist", "gsr::k_part_count": "depth_partition",
+    "gsr::k_part_scatter": "depth_partition", "gsr::k_chunk_sort_small": "chunk_sort", "gsr::k_zero_segments": "zero_outputs",
+    "gsr::k_act_fwd": "activations_fwd", "gsr::k_act_bwd": "activations_bwd",
 }
 SKIP_FIRST = 3
 
