@@ -536,6 +536,8 @@ __global__ __launch_bounds__(kGatherBlock) void k_tile_gather(FrameK f, int c, i
                                                               uint32_t *__restrict__ sorted_slot, uint32_t *__restrict__ row_begin)
 {
     __shared__ uint4 sh_meta[kGatherBlock];
+    __shared__ uint32_t sh_rank[kGatherBlock];
+    __shared__ uint32_t sh_wcnt[kGatherBlock / kWave];
     __shared__ uint2 sh_q[kGatherBlock / kWave][2 * kWave];    // per tile: ranks whose rectangle holds it, waiting for a full wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t base = ctrl->chunk_base[c];
@@ -548,38 +550,57 @@ __global__ __launch_bounds__(kGatherBlock) void k_tile_gather(FrameK f, int c, i
         }
     }
     if (nothing) return;
+    constexpr int kTiles = kGatherBlock / kWave;
     const int slab_tiles = (f.ty1 - f.ty0) * f.Gx;
-    const int t_local = (int)blockIdx.x * (kGatherBlock / kWave) + wv;
-    if ((int)blockIdx.x * (kGatherBlock / kWave) >= slab_tiles) return;       // block-uniform
+    const int t_first = (int)blockIdx.x * kTiles;
+    if (t_first >= slab_tiles) return;                           // block-uniform
+    const int t_local = t_first + wv;
     const int tile = f.ty0 * f.Gx + t_local;
     uint2 rng = make_uint2(0u, 0u);
     if (t_local < slab_tiles) rng = ranges_c[tile];
+    if (__syncthreads_or(rng.y != rng.x) == 0) return;           // none of the block's tiles takes anything in this chunk
     const int ty = tile / f.Gx, tx = tile - ty * f.Gx;
+    // bounding box of the block's tiles (consecutive in row-major order: one row, or the end of one and the start of the next):
+    // a rank whose rectangle misses it is dropped for all eight tiles at once
+    const int t_last = min(t_first + kTiles, slab_tiles) - 1;
+    const int by0 = f.ty0 + t_first / f.Gx, by1 = f.ty0 + t_last / f.Gx;
+    const int bx0 = by0 == by1 ? t_first % f.Gx : 0, bx1 = by0 == by1 ? t_last % f.Gx : f.Gx - 1;
     const unsigned long long below = (1ull << lane) - 1ull;
     uint2 *q = sh_q[wv];
     uint32_t out = rng.x;
     int qn = 0;                                                // wave-uniform
     uint4 next = (int)threadIdx.x < n ? meta_a[threadIdx.x] : make_uint4(0u, 0u, 0u, 0u);
     for (int k0 = 0; k0 < n; k0 += kGatherBlock) {
-        __syncthreads();
-        sh_meta[threadIdx.x] = next;
-        __syncthreads();
+        const uint4 mine = next;                                 // w = h = 0 (past the end): never inside
         {
             const int r = k0 + kGatherBlock + (int)threadIdx.x;
-            next = r < n ? meta_a[r] : make_uint4(0u, 0u, 0u, 0u);           // w = h = 0: never inside
+            next = r < n ? meta_a[r] : make_uint4(0u, 0u, 0u, 0u);
         }
+        const int x0 = (int)(mine.x & 0xFFFFu), y0 = (int)(mine.x >> 16), w = (int)(mine.y & 0xFFFFu), h = (int)(mine.y >> 16);
+        const bool keep = w > 0 && x0 <= bx1 && x0 + w > bx0 && y0 <= by1 && y0 + h > by0;
+        const unsigned long long mk = __ballot(keep);
+        __syncthreads();                                         // (the previous batch's survivors have been read)
+        if (lane == 0) sh_wcnt[wv] = (uint32_t)__popcll(mk);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < kTiles; ++i) { const uint32_t v = sh_wcnt[i]; if (i < wv) before += v; total += v; }
+        if (keep) {
+            const uint32_t p = before + (uint32_t)__popcll(mk & below);
+            sh_meta[p] = mine; sh_rank[p] = (uint32_t)(k0 + (int)threadIdx.x);
+        }
+        __syncthreads();
         if (out >= rng.y) continue;                            // this tile's list is complete (or empty); keep the barriers
-#pragma unroll 2
-        for (int u = 0; u < kGatherBlock / kWave; ++u) {
-            if (k0 + u * kWave >= n) break;
-            const uint4 ma = sh_meta[u * kWave + lane];
-            const uint32_t dx = (uint32_t)tx - (ma.x & 0xFFFFu), dy = (uint32_t)ty - (ma.x >> 16), w = ma.y & 0xFFFFu;
-            const bool in = dx < w && dy < (ma.y >> 16);
+        for (uint32_t u = 0; u < total; u += kWave) {
+            const bool have = u + (uint32_t)lane < total;
+            const uint4 ma = have ? sh_meta[u + lane] : make_uint4(0u, 0u, 0u, 0u);
+            const uint32_t dx = (uint32_t)tx - (ma.x & 0xFFFFu), dy = (uint32_t)ty - (ma.x >> 16), ww = ma.y & 0xFFFFu;
+            const bool in = dx < ww && dy < (ma.y >> 16);
             const unsigned long long m_in = __ballot(in);
             if (m_in == 0ull) continue;
             if (in) {
-                const uint32_t idx = dy * w + dx;
-                q[qn + __popcll(m_in & below)] = make_uint2(ma.z + (idx >> 6), ((uint32_t)(k0 + u * kWave + lane) << 6) | (idx & 63u));
+                const uint32_t idx = dy * ww + dx;
+                q[qn + __popcll(m_in & below)] = make_uint2(ma.z + (idx >> 6), (sh_rank[u + lane] << 6) | (idx & 63u));
             }
             qn += __popcll(m_in);
             if (qn >= kWave) {
