@@ -82,7 +82,8 @@ typedef struct gsr_frame_plan {
                                                      the chunks are SELECTED by depth; each is sorted when it is binned  */
     int32_t chunks_sorted;                        /* chunks [0, chunks_sorted) of the depth order are already sorted: a re-run of
                                                      gsr_forward_render (after GSR_ERR_WORKSPACE) does not sort them again   */
-    int32_t reserved_;
+    int32_t chunks_filtered;                      /* bit c: chunk c was put through the live filter (only the Gaussians that can still
+                                                     reach an open tile sit at the front of its range, sorted and binned)        */
 } gsr_frame_plan;
 
 typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */

@@ -308,6 +308,8 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
     plan->binning_initialised = 0;                  // a re-run of this stage must reset the tile ranges / open flags itself
     int sort_result = 0;
     uint64_t emitted_before = 0;                    // instances earlier chunks emitted (exact: read back with the open-tile count)
+    uint32_t open_now = 0xFFFFFFFFu;                // tiles still open before the current chunk (known from chunk 1 on)
+    constexpr int kLiveFilterMin = 1 << 16;         // the filter's launches pay off from this many Gaussians on
     // Early stop: one control-block readback per chunk (~10 us of stream idle, measured); the chunk plan keeps
     // the number of chunks at three or fewer.
     for (int c = 0; c < plan->num_chunks; ++c) {
@@ -321,12 +323,22 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         }
         // the chunk's Gaussians were selected by depth; now that it is needed, put them in (depth, index) order
         // (once: a re-run of this stage after GSR_ERR_WORKSPACE finds the earlier chunks sorted, and the sort's inputs consumed)
+        // A late, large chunk with most tiles closed (a frame with a corner no splat covers runs every chunk, and the last one is
+        // most of the scene): first move the Gaussians whose rectangle still holds an open tile to the front of its range
+        // (launch_live_filter) — only those get sorted and binned, one wave each.
+        const uint64_t chunk_n = (uint64_t)(r1 - r0), chunk_max = (uint64_t)plan->chunk_instances_max[c];
+        const bool filtered = c > 0 && r1 - r0 >= kLiveFilterMin && (long long)open_now * 2 < (long long)(f.ty1 - f.ty0) * f.Gx &&
+                              chunk_max / 32 + 2 * chunk_n + 4 <= chunk_max && !getenv("GSR_NO_LIVE_FILTER");
+        if (filtered) plan->chunks_filtered |= 1 << c;
         if (c >= plan->chunks_sorted) {
-            if ((rc = launch_chunk_order(f, r0, r1, c > 0 ? plan->chunk_key_end[c - 1] : 0u, plan->chunk_key_end[c], c == 0, gw, dbg, s))) return rc;
+            if (filtered && (rc = launch_live_filter(f, c, r0, r1, gw, iw, dbg, s))) return rc;
+            if ((rc = launch_chunk_order(f, r0, r1, c > 0 ? plan->chunk_key_end[c - 1] : 0u, plan->chunk_key_end[c], c == 0, gw, dbg, s,
+                                         filtered ? &gw.ctrl->chunk_live[c] : nullptr)))
+                return rc;
             plan->chunks_sorted = c + 1;
         }
-        if ((rc = launch_chunk_binning(f, c, r0, r1, (uint64_t)plan->chunk_instances_max[c], emitted_before, gw, bw, iw, &sort_result,
-                                       dbg, s)))
+        if ((rc = launch_chunk_binning(f, c, r0, r1, chunk_max, emitted_before, gw, bw, iw, &sort_result, dbg, s,
+                                       (plan->chunks_filtered >> c) & 1)))
             return rc;
         if ((rc = launch_chunk_colors(f, *cam, *g, r0, r1, plan->num_visible, gw, dbg, s))) return rc;      // A.6 for this chunk's Gaussians only
         if ((rc = launch_render_fwd(f, *cam, c, last, gw, bw, iw, out_color, dbg, s))) return rc;
@@ -338,6 +350,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         if ((rc = read_ctrl(gw.ctrl, &h, s))) return rc;
         plan->instances_emitted = (int64_t)h.chunk_base[c + 1];
         emitted_before = (uint64_t)h.chunk_base[c + 1];
+        open_now = h.open_count;
         if (h.open_count == 0) break;
     }
     plan->sort_result = sort_result;

@@ -167,15 +167,20 @@ __global__ __launch_bounds__(W *kWave) void k_count_team(FrameK f, int c, int r0
                                                          const Ctrl *__restrict__ ctrl, const uint32_t *__restrict__ offs_full,
                                                          unsigned long long *__restrict__ masks, uint32_t *__restrict__ cnt_open,
                                                          uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ wprefix,
-                                                         uint4 *__restrict__ meta_a, float4 *__restrict__ meta_b)
+                                                         uint4 *__restrict__ meta_a, float4 *__restrict__ meta_b, int n_total)
 {
     constexpr int T = W * kWave;
     __shared__ uint32_t sh_cnt[W];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = r0 + (int)blockIdx.x;
+    // one block per Gaussian; a chunk the live filter went through is walked by a fixed grid instead (n_total blocks would mostly
+    // be Gaussians that cannot emit: their counts were cleared by the launcher, and the walk stops at the last live one)
+    const uint32_t live = ctrl->chunk_live[c];
+    for (int rk = (int)blockIdx.x; rk < n_total; rk += (int)gridDim.x) {
+    const int r = r0 + rk;
+    if ((uint32_t)rk >= live) break;
     if (c > 0 && ctrl->open_count == 0u) {                     // a speculatively enqueued chunk: nothing is open
         if (threadIdx.x == 0) cnt_open[r] = 0;
-        return;
+        continue;
     }
     const uint32_t g = order[r];
     const float4 a = records[3 * (size_t)g], b = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
@@ -239,6 +244,8 @@ __global__ __launch_bounds__(W *kWave) void k_count_team(FrameK f, int c, int r0
             carry += wtot;
         }
     }
+    if (W > 1 || GATHER) __syncthreads();                   // (LDS of this Gaussian is done with before the next one)
+    }
 }
 
 template <int W>
@@ -248,20 +255,23 @@ __global__ __launch_bounds__(W *kWave) void k_emit_team(FrameK f, int c, int r0,
                                                         const unsigned long long *__restrict__ masks,
                                                         const uint32_t *__restrict__ cnt_open, const uint32_t *__restrict__ offs_open,
                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                        uint32_t *__restrict__ inst_gid, uint32_t *__restrict__ row_begin)
+                                                        uint32_t *__restrict__ inst_gid, uint32_t *__restrict__ row_begin, int n_total)
 {
     constexpr int T = W * kWave;
     __shared__ unsigned long long sh_m[T];
     __shared__ uint32_t sh_off[T];
     __shared__ uint32_t sh_wave[W];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = r0 + (int)blockIdx.x;
     const uint32_t base = ctrl->chunk_base[c];
     const bool nothing = ctrl->chunk_R[c] == 0u;
+    const uint32_t live = ctrl->chunk_live[c];                   // (see k_count_team: a fixed grid walks a filtered chunk)
+    for (int rk = (int)blockIdx.x; rk < n_total; rk += (int)gridDim.x) {
+    if ((uint32_t)rk >= live) break;
+    const int r = r0 + rk;
     const uint32_t cnt = nothing ? 0u : cnt_open[r];
     const uint32_t first = base + (nothing ? 0u : offs_open[r] - cnt);
     if (threadIdx.x == 0) row_begin[r] = first;
-    if (cnt == 0u) return;
+    if (cnt == 0u) continue;
     const uint32_t g = order[r];
     const float4 ra = records[3 * (size_t)g], rb = records[3 * (size_t)g + 1], cc = records[3 * (size_t)g + 2];
     const TileRect t = unpack_rect(cc.z, cc.w);
@@ -305,6 +315,7 @@ __global__ __launch_bounds__(W *kWave) void k_emit_team(FrameK f, int c, int r0,
         }
         carry += wtot;
         __syncthreads();
+    }
     }
 }
 
@@ -374,7 +385,7 @@ __global__ __launch_bounds__(kBinBlock) void k_bin_chunk(FrameK f, int c, int r0
             alive = cnt != 0u;
         }
     } else {
-        alive = mine && !(c > 0 && ctrl->open_count == 0u);
+        alive = mine && !(c > 0 && ctrl->open_count == 0u) && (uint32_t)(r - r0) < ctrl->chunk_live[c];
     }
     if (alive) {
         g = order[r];
@@ -623,6 +634,130 @@ __global__ __launch_bounds__(kGatherBlock) void k_tile_gather(FrameK f, int c, i
     }
 }
 
+// ---- late chunks: most tiles have closed, so most of the chunk's Gaussians can no longer emit anything, yet sorting,
+// scanning and counting would still walk all of them (the last chunk of a frame with an uncovered corner is most of the
+// scene).  Before such a chunk is sorted, a stable two-way partition of its range puts the Gaussians whose rectangle still
+// holds an open tile in front; ctrl->chunk_live[c] = how many.  The sort and the binning (one wave per Gaussian: the
+// survivors all have work, and there are few of them) touch the front part only; the others stay in the depth order
+// behind them, unsorted, with an instance count of zero.
+constexpr int kLiveThreads = 512;
+constexpr int kLiveWaves = kLiveThreads / kWave;
+
+__device__ __forceinline__ void live_block_range(int n, int &lo, int &hi)
+{
+    int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+    per = (per + kLiveThreads - 1) / kLiveThreads * kLiveThreads;
+    const long long l = (long long)blockIdx.x * per;
+    lo = l < n ? (int)l : n;
+    hi = l + per < n ? (int)(l + per) : n;
+}
+
+// pass 1: one flag byte per position + the live count of every block
+__global__ __launch_bounds__(kLiveThreads) void k_live_flags(FrameK f, int r0, int n, const uint32_t *__restrict__ order,
+                                                             const float4 *__restrict__ records,
+                                                             const unsigned long long *__restrict__ open_bits, SelState *st,
+                                                             uint8_t *__restrict__ flags)
+{
+    __shared__ unsigned long long sh_bits[kBitsMaxWords];
+    __shared__ uint32_t sh_cnt;
+    const int W64 = (f.Gx + 63) >> 6, n_words = f.Gy * W64;
+    const bool in_lds = n_words <= kBitsMaxWords;
+    if (in_lds)
+        for (int j = threadIdx.x; j < n_words; j += kLiveThreads) sh_bits[j] = open_bits[j];
+    if (threadIdx.x == 0) sh_cnt = 0;
+    __syncthreads();
+    const unsigned long long *bits = in_lds ? sh_bits : open_bits;
+    int lo, hi;
+    live_block_range(n, lo, hi);
+    uint32_t mine = 0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += kLiveThreads) {
+        const float4 cc = records[3 * (size_t)order[r0 + i] + 2];
+        const bool live = rect_has_open_tile(unpack_rect(cc.z, cc.w), bits, W64);
+        flags[i] = live ? 1 : 0;
+        mine += live ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&sh_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) st->blk_cnt[0][blockIdx.x] = sh_cnt;
+}
+
+// pass 2: live Gaussians to the front, the others behind them, both in their old order; (Gaussian, relative key, tiles) move together
+__global__ __launch_bounds__(kLiveThreads) void k_live_scatter(int c, int r0, int n, const uint32_t *__restrict__ order,
+                                                               const uint32_t *__restrict__ pos_key, const uint32_t *__restrict__ pos_tiles,
+                                                               const uint8_t *__restrict__ flags, const SelState *__restrict__ st, Ctrl *ctrl,
+                                                               uint32_t *__restrict__ t_order, uint32_t *__restrict__ t_key,
+                                                               uint32_t *__restrict__ t_tiles)
+{
+    __shared__ uint32_t sh_w[2][kLiveWaves], sh_pre[2][kLiveWaves], sh_run[2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv < 2) {                                                // wave 0: live Gaussians in the blocks before this one; wave 1: all live
+        uint32_t s = 0;
+        const int upto = wv == 0 ? (int)blockIdx.x : (int)gridDim.x;
+        for (int b = lane; b < upto; b += kWave) s += st->blk_cnt[0][b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += (uint32_t)__shfl_xor((int)s, off);
+        if (lane == 0) sh_run[wv] = s;
+    }
+    __syncthreads();
+    int lo, hi;
+    live_block_range(n, lo, hi);
+    const uint32_t live_total = sh_run[1];
+    uint32_t live_before = sh_run[0], dead_before = (uint32_t)lo - live_before;
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->chunk_live[c] = live_total;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int i0 = lo; i0 < hi; i0 += kLiveThreads) {
+        const int i = i0 + (int)threadIdx.x;
+        const bool valid = i < hi;
+        const bool live = valid && flags[i] != 0;
+        const unsigned long long m = __ballot(live), mv = __ballot(valid);
+        __syncthreads();                                         // (sh_pre / sh_run of the previous round have been read)
+        if (lane == 0) { sh_w[0][wv] = (uint32_t)__popcll(m); sh_w[1][wv] = (uint32_t)__popcll(mv & ~m); }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+            uint32_t run = threadIdx.x == 0 ? live_before : live_total + dead_before;
+#pragma unroll
+            for (int w = 0; w < kLiveWaves; ++w) { sh_pre[threadIdx.x][w] = run; run += sh_w[threadIdx.x][w]; }
+            sh_run[threadIdx.x] = run;
+        }
+        __syncthreads();
+        if (valid) {
+            const uint32_t pos = live ? sh_pre[0][wv] + (uint32_t)__popcll(m & below) : sh_pre[1][wv] + (uint32_t)__popcll(mv & ~m & below);
+            t_order[pos] = order[r0 + i]; t_key[pos] = pos_key[r0 + i]; t_tiles[pos] = pos_tiles[r0 + i];
+        }
+        live_before = sh_run[0]; dead_before = sh_run[1] - live_total;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_live_copyback(int n, const uint32_t *__restrict__ t_order, const uint32_t *__restrict__ t_key,
+                                                       const uint32_t *__restrict__ t_tiles, uint32_t *__restrict__ order,
+                                                       uint32_t *__restrict__ pos_key, uint32_t *__restrict__ pos_tiles)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    order[i] = t_order[i]; pos_key[i] = t_key[i]; pos_tiles[i] = t_tiles[i];
+}
+
+int launch_live_filter(const FrameK &f, int c, int r0, int r1, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
+{
+    const int n = r1 - r0;
+    if (n <= 0) return GSR_OK;
+    ProfileScope prof("live_filter", s);
+    int blocks = (n + kLiveThreads * 4 - 1) / (kLiveThreads * 4);
+    if (blocks > kSelBlocks) blocks = kSelBlocks;
+    // scratch: the chunk's own by-rank arrays, unused until its binning starts; the flags in the radix table area
+    uint32_t *t_order = gw.offs_open + r0, *t_key = gw.row_begin + r0, *t_tiles = gw.cnt_open + r0;
+    uint8_t *flags = reinterpret_cast<uint8_t *>(gw.offs_full + r0);          // n bytes of the chunk's (not yet written) tile-count scan
+    hipLaunchKernelGGL(k_live_flags, dim3(blocks), dim3(kLiveThreads), 0, s, f, r0, n, gw.order, gw.records, iw.open_bits, gw.sel, flags);
+    hipLaunchKernelGGL(k_live_scatter, dim3(blocks), dim3(kLiveThreads), 0, s, c, r0, n, gw.order, gw.sort_keys[1], gw.sort_vals[1], flags,
+                       gw.sel, gw.ctrl, t_order, t_key, t_tiles);
+    hipLaunchKernelGGL(k_live_copyback, dim3((n + 255) / 256), dim3(256), 0, s, n, t_order, t_key, t_tiles, gw.order + r0, gw.sort_keys[1] + r0,
+                       gw.sort_vals[1] + r0);
+    GSR_LAUNCH_CHECK("live_filter", debug, s);
+    return GSR_OK;
+}
+
 // ---- ranges of the chunk's sorted list (grid-stride, element count on the device)
 __global__ __launch_bounds__(kBinBlock) void k_ranges(int c, const Ctrl *__restrict__ ctrl, const uint32_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ slots, const uint32_t *__restrict__ inst_gid,
@@ -651,7 +786,7 @@ static int msb_plus1(uint32_t n)
 
 int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, uint64_t emitted_before, GeomWS &gw, BinningWS &bw,
                          ImageWS &iw,
-                         int *sort_result, bool debug, hipStream_t s)
+                         int *sort_result, bool debug, hipStream_t s, bool filtered)
 {
     int rc;
     const int n = r1 - r0;
@@ -660,8 +795,10 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     // variant B packs the (Gaussian, tile) candidates of 64 Gaussians into full wave steps: right when rectangles are
     // small; chunks of few large splats (the nearest ones) get a team of 1, 4 or 16 waves per Gaussian (variant A)
     const uint64_t avg = n_max / (uint64_t)n;
-    const bool flat = avg < 24;
-    const int team = avg >= 1024 ? 16 : avg >= 96 ? 4 : 1;
+    // a chunk the live filter went through: few survivors, every one of them with work -> one wave per Gaussian whatever the
+    // rectangle size (64 ranks per wave would leave a handful of long-running waves); its mask scratch fits (the caller checked)
+    const bool flat = avg < 24 && !filtered;
+    const int team = filtered ? 1 : avg >= 1024 ? 16 : avg >= 96 ? 4 : 1;
     const int bin_blocks = (n + kBinBlock - 1) / kBinBlock;      // B: 64 depth ranks per wave, 4 waves per block
     // A's mask scratch: the idle half of the radix double buffer beyond everything earlier chunks have written (their exact
     // emitted count; ceil(n_max / 64) + n words of 8 bytes fit in the n_max slots the caller has checked are there: a team
@@ -671,18 +808,21 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     // scratch (mask prefixes, rank metadata: n_max / 64 + 9 n + 4 words) sits in the other idle key buffer
     const uint64_t slab_tiles = (uint64_t)(f.ty1 - f.ty0) * (uint64_t)f.Gx;
     const uint64_t scratch_words = n_max / 64 + 1 + 9 * (uint64_t)n + 4;
-    const bool gather = !flat && !getenv("GSR_NO_GATHER") && n < (1 << 26) && (uint64_t)n * slab_tiles <= 24 * n_max + (1ull << 22) &&
+    const bool gather = !flat && !filtered && !getenv("GSR_NO_GATHER") && n < (1 << 26) && (uint64_t)n * slab_tiles <= 24 * n_max + (1ull << 22) &&
                         scratch_words <= n_max;
     uint32_t *scratch = bw.keys[0] + ((emitted_before + 3) & ~(uint64_t)3);
     uint4 *meta_a = reinterpret_cast<uint4 *>(scratch);
     float4 *meta_b = reinterpret_cast<float4 *>(scratch + 4 * (size_t)n);
     uint32_t *wprefix = scratch + 8 * (size_t)n;
     const int tile_bits = msb_plus1((uint32_t)(Tn ? Tn - 1 : 0));
+    // a filtered chunk: a fixed grid walks the live front part; everybody else's count is zero from the start
+    const int team_grid = filtered ? (n < 16384 ? n : 16384) : n;
+    if (filtered) GSR_HIP_CHECK(hipMemsetAsync(gw.cnt_open + r0, 0, (size_t)n * sizeof(uint32_t), s));
     {
         ProfileScope prof("count_open", s);
 #define GSR_CT(W, G)                                                                                                       \
-    hipLaunchKernelGGL((k_count_team<W, G>), dim3(n), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, iw.open_bits, gw.ctrl, \
-                       gw.offs_full, masks, gw.cnt_open, iw.tile_cnt, wprefix, meta_a, meta_b)
+    hipLaunchKernelGGL((k_count_team<W, G>), dim3(team_grid), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, iw.open_bits, gw.ctrl, \
+                       gw.offs_full, masks, gw.cnt_open, iw.tile_cnt, wprefix, meta_a, meta_b, n)
         if (flat)
             hipLaunchKernelGGL(k_bin_chunk<false>, dim3(bin_blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records,
                                iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);
@@ -716,8 +856,8 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     {
         ProfileScope prof("emit", s);
 #define GSR_ET(W)                                                                                                          \
-    hipLaunchKernelGGL(k_emit_team<W>, dim3(n), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, gw.ctrl, gw.offs_full,  \
-                       masks, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin)
+    hipLaunchKernelGGL(k_emit_team<W>, dim3(team_grid), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, gw.ctrl, gw.offs_full,  \
+                       masks, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin, n)
         if (flat)
             hipLaunchKernelGGL(k_bin_chunk<true>, dim3(bin_blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records,
                                iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);

@@ -99,6 +99,8 @@ struct Ctrl {                   // small device-side control block of one frame
     uint32_t chunk_full[GSR_MAX_CHUNKS];       // instances of the chunk if every tile were open
     uint32_t chunk_R[GSR_MAX_CHUNKS];          // instances actually emitted
     uint32_t chunk_base[GSR_MAX_CHUNKS + 1];   // first absolute instance index of the chunk
+    uint32_t chunk_live[GSR_MAX_CHUNKS];       // Gaussians at the front of the chunk's range that can still reach an open tile
+                                               // (0xFFFFFFFF: the chunk was not filtered, all of them)
     uint32_t overflow;                         // 1 = the sum of tiles touched does not fit 32 bits
     uint32_t prefilter_violation;              // 1 = prefiltered was set and a Gaussian failed the frustum test (A.1)
 };
@@ -167,13 +169,15 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
                       bool prefiltered, bool debug, hipStream_t s);
 int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
-int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_t key_hi, bool first, GeomWS &ws, bool debug, hipStream_t s);
+int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_t key_hi, bool first, GeomWS &ws, bool debug, hipStream_t s,
+                       const uint32_t *live_count = nullptr);
+int launch_live_filter(const FrameK &f, int c, int r0, int r1, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
 int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, int num_visible, GeomWS &ws,
                         bool debug, hipStream_t s);
 int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, uint64_t emitted_before, GeomWS &gw, BinningWS &bw,
                          ImageWS &iw,
-                         int *sort_result, bool debug, hipStream_t s);
+                         int *sort_result, bool debug, hipStream_t s, bool filtered = false);
 int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s);

@@ -166,7 +166,7 @@ __device__ void sel_plan2(unsigned long long first_mass, const SelState *st, Ctr
     for (int k = 0; k < GSR_MAX_CHUNKS; ++k) out_ends[k] = p_key[k];
     if (!write) return;
     for (int k = 0; k < GSR_MAX_CHUNKS; ++k) { ctrl->key_end[k] = p_key[k]; ctrl->bnd[k + 1] = p_cnt[k]; ctrl->chunk_full[k] = p_full[k]; }
-    for (int k = 0; k < GSR_MAX_CHUNKS; ++k) { ctrl->chunk_R[k] = 0; ctrl->chunk_base[k + 1] = 0; }
+    for (int k = 0; k < GSR_MAX_CHUNKS; ++k) { ctrl->chunk_R[k] = 0; ctrl->chunk_base[k + 1] = 0; ctrl->chunk_live[k] = 0xFFFFFFFFu; }
     ctrl->bnd[0] = 0; ctrl->chunk_base[0] = 0;
     ctrl->V = V;
     ctrl->R_total = R > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)R;
@@ -574,7 +574,10 @@ static int bits_of(uint32_t v)
     return b;
 }
 
-int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_t key_hi, bool first, GeomWS &ws, bool debug, hipStream_t s)
+// live_count (device): only the first *live_count Gaussians of the range need sorting (launch_live_filter put the ones that
+// can still reach an open tile in front); the rest keep their place behind them
+int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_t key_hi, bool first, GeomWS &ws, bool debug, hipStream_t s,
+                       const uint32_t *live_count)
 {
     const int n = r1 - r0;
     if (n <= 0) return GSR_OK;
@@ -583,7 +586,7 @@ int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_
     const uint32_t base = sel_key_base(key_lo, first);
     int bits = bits_of(key_hi > base ? key_hi - base : 0u);
     if (bits < 1) bits = 1;
-    if (n <= kSmallSortMax) {
+    if (n <= kSmallSortMax && !live_count) {
         const int force_radix = getenv("GSR_SORT_FORCE_RADIX") ? 1 : 0;               // test hook: the fallback path of the LDS sort
         ProfileScope prof("chunk_sort", s);
         hipLaunchKernelGGL(k_chunk_sort_small, dim3(1), dim3(kSmallThreads), 0, s, n, (uint32_t)r0, bits, force_radix, ws.sort_keys[1],
@@ -595,7 +598,7 @@ int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_
     // ping-pong between (sort_keys[1], order) and (cnt_open, sort_vals[1]); an even number of passes ends in the first pair
     uint32_t *kbuf[2] = {ws.sort_keys[1] + r0, ws.cnt_open + r0};
     uint32_t *vbuf[2] = {ws.order + r0, ws.sort_vals[1] + r0};
-    if ((rc = launch_radix_sort<uint32_t>(kbuf, vbuf, nullptr, (uint32_t)n, (uint64_t)n, nullptr, 0, bits, ws.radix_temp, &result, "chunk_sort",
+    if ((rc = launch_radix_sort<uint32_t>(kbuf, vbuf, live_count, (uint32_t)n, (uint64_t)n, nullptr, 0, bits, ws.radix_temp, &result, "chunk_sort",
                                           debug, s, /*even_passes=*/true)))
         return rc;
     if (result != 0) { set_error("internal: chunk sort result buffer %d", result); return GSR_ERR_HIP; }

@@ -1211,3 +1211,43 @@ def test_getter_fusion_is_transparent():
     finally:
         dgr.FUSE_GETTERS = False
         dgr._RasterizeGaussiansRaw.apply = orig
+
+
+def test_frame_with_an_uncovered_region_runs_the_live_filter_and_matches_the_oracle():
+    """A frame whose lower half no splat covers: those tiles never close, every planned chunk runs, and the late chunks are most of
+    the scene.  They go through the live filter (csrc/gsr_binning.hip k_live_*: only the Gaussians whose rectangle still holds an
+    open tile are sorted and binned, one wave each; plan.chunks_filtered).  Pixels and every gradient against the fp64 oracle, and
+    the depth order stays a permutation of the visible set with the filtered chunks' live part sorted in front."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _native as N
+    W, H, P = 480, 320, 260_000
+    scene = S.make_scene(P, W, H, 1, 91, scale_lo=0.01, scale_hi=0.07)
+    scene.means3D[:, 1] = -scene.means3D[:, 1].abs() - 0.02 * scene.means3D[:, 2]            # everything in the upper half
+    cam = S.make_camera(W, H)
+    kw = raster_kwargs(scene, cam)
+    rs, inp = _settings(kw), _inputs(kw, False)
+    color, radii, fr = dgr.rasterize_forward(inp["means3D"], inp["shs"], None, inp["opacities"], inp["scales"], inp["rotations"], None, rs)
+    torch.cuda.synchronize()
+    plan = fr.plan
+    assert plan.num_chunks >= 2 and plan.chunks_run == plan.num_chunks and plan.chunks_filtered != 0, (plan.num_chunks, plan.chunks_run, plan.chunks_filtered)
+    v = N.debug_views(fr.desc, fr.geom_ws, fr.binning_ws, fr.image_ws, plan)
+    V = plan.num_visible
+    order = v["depth_order"][:V].long()
+    assert int(torch.unique(order).numel()) == V
+    depth = v["splat_records"][:, 9]
+    for c in range(plan.num_chunks):
+        if (plan.chunks_filtered >> c) & 1:
+            b0, b1 = int(plan.chunk_rank_begin[c]), int(plan.chunk_rank_begin[c + 1])
+            lists = v["sorted_gaussian"].long()
+            rng = v["ranges"][c].long()
+            used = torch.unique(torch.cat([lists[a:b] for a, b in rng.tolist() if b > a] or [lists[:0]]))
+            pos = torch.full((fr.desc.P,), -1, dtype=torch.long, device=DEV)
+            pos[order[b0:b1]] = torch.arange(b1 - b0, device=DEV)
+            n_live_max = int(pos[used].max()) + 1 if used.numel() else 0
+            assert 0 < n_live_max < (b1 - b0) // 2, (c, n_live_max, b1 - b0)           # the binned ones sit in front ...
+            d = depth[order[b0:b0 + n_live_max]]
+            assert bool((d[1:] >= d[:-1]).all())                                          # ... in depth order
+    fr64 = oracle.rasterize(dtype=np.float64, parallel=True, **kw)
+    gimg = S.make_grad_image(W, H, 4).numpy()
+    *_, live = _forward_backward_strict(kw, fr64, gimg, label="uncovered half", parallel=True)
+    assert live > 1000
