@@ -5,7 +5,8 @@
 
 A "step" is the reference's timed training window (train.py:79-108): render() through the drop-in
 rasterizer + L1/D-SSIM loss + backward into the leaf parameters, on BASELINE.json configs[2]'s scene
-(1e6 Gaussians, 1920x1080, SH degree 3; SURVEY Appendix B, seed 3).  Inputs are resident in HBM before
+(1e6 Gaussians, 1920x1080, SH degree 3; SURVEY Appendix B, seed 3).  The parameter store is this package's
+scene.GaussianModel (the reference class's surface, getters as native ops: SURVEY 8a row a14).  Inputs are resident in HBM before
 the timed region.  For N > 1 the image is split into tile-row slabs: the scene is fixed and each
 rank renders its slab of the SAME image, so scaling is "strong".  `python bench.py --gpus N` without a launcher
 starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself (as a child process).
@@ -17,6 +18,8 @@ Prints ONE JSON line on rank 0.  Besides the contract's keys:
   cpu_baseline  the CPU oracle (a port, test infrastructure) on rank 0 at N = 1 only; .cfg1 = BASELINE configs[0]
   secondary     the same step on a NON-saturating scene (scene_synth CONFIGS["cfg3n"]: R/P = 3.6, 98 % of the visible
                 Gaussians receive a gradient) with its own per-kernel table and roofline, and cfg3 with another seed
+  torch_getters the same step over a store whose getters are the reference's torch ops (gaussian_params.GaussianParams):
+                what a caller who keeps the reference's own GaussianModel class gets from the drop-in rasterizer alone
   reference_loss_composition   the step with the reference's own two-call loss (l1_loss + ssim: utils/loss_utils.py)
 """
 import argparse

@@ -7,17 +7,19 @@
 // all 256 pixels below the 1e-4 transmittance cut-off after the nearest ~0.3 % of the Gaussians; only
 // 1.4 M of the 43.8 M instances can ever touch a pixel.  So:
 //
-//   1. sort the P Gaussians ONCE by depth (32-bit keys, invisible ones last)           [P-sized]
-//   2. inclusive scan of tiles touched in depth order; plan depth chunks by cumulative OPTICAL MASS: a pixel takes
-//      the transmittance cut-off once the optical depths in front of it sum to ln(1e4) = 9.21, so the first chunk
-//      ends where the frame's mean optical depth (running sum of the splats' optical masses / slab pixels,
-//      gsr_math.h optical_mass) reaches kChunkOpticalDepths x 9.21, each further one at 4x more; a frame whose
-//      total never gets there (a scene that does not saturate) is ONE chunk.  Every chunk costs ~16 small
-//      launches (~100 us of fixed time) while an instance costs ~0.1 ns, so few and large chunks win   [P-sized]
-//   3. per chunk: count the instances each Gaussian emits (tiles of its rectangle that are OPEN and that its
-//      alpha >= 1/255 ellipse can reach: exact tile culling), scan, emit (tile id, slot) pairs in depth
-//      order, stable radix sort on the tile id only (2 passes of 8 bits), tile ranges, blend
-//      (gsr_render.hip), recount the open tiles.
+//   1. select depth chunks WITHOUT sorting (gsr_select.hip): a histogram of the depth keys carries tile counts and
+//      OPTICAL MASS per bin; a pixel takes the transmittance cut-off once the optical depths in front of it sum to
+//      ln(1e4) = 9.21, so the first chunk ends at the key where the frame's mean optical depth (running sum of the
+//      splats' optical masses / slab pixels, gsr_math.h optical_mass) reaches kChunkOpticalDepths x 9.21, each further
+//      one at 4x more; a frame whose total never gets there (a scene that does not saturate) is ONE chunk.  Every
+//      chunk costs ~16 small launches (~100 us of fixed time) while an instance costs ~0.1 ns, so few and large
+//      chunks win.  A stable partition groups the Gaussians by chunk                                       [P-sized]
+//   2. per chunk: sort ITS Gaussians by (depth, index) (one block in LDS, or the radix sort), count the instances
+//      each Gaussian emits (tiles of its rectangle that are OPEN and that its alpha >= 1/255 ellipse can reach: exact
+//      tile culling), scan, then the per-tile lists in depth order: by GATHER for chunks of few large splats (one
+//      wave per tile collects its ranks), else emit (tile id, slot) pairs in depth order + stable radix sort on the
+//      tile id only + tile ranges; blend (gsr_render.hip), recount the open tiles.  Late chunks of frames that never
+//      close first go through the live filter (below).
 //      The host reads back ONE word per chunk (open tiles left) and stops when it is zero.
 //
 // A tile is closed only when every pixel has taken the A.8 cut-off, after which no further splat can
@@ -35,11 +37,8 @@ namespace gsr {
 // closed at a mean of 1.9 cut-off depths, 99 % at 3.3 and the last one at 4.0-4.3 (measured with the oracle on cfg2,
 // cfg3, a second seed and off-axis cameras: the mass counts the faint skirts below alpha = 1/255 that the blend
 // skips, hence > 1).  5 leaves a margin; regions the splats cover unevenly simply close in the next, 4x larger, chunk.
-// (now in gsr_internal.h) constexpr float kCutoffOpticalDepth = 9.2103404f;
-// (now in gsr_internal.h) constexpr float kChunkOpticalDepths = 5.f;
-// (now in gsr_internal.h) constexpr uint32_t kMinFirstChunk = 1u << 18;
-                                                 // a chunk's fixed cost is worth a few hundred thousand instances
-// (now in gsr_internal.h) constexpr int kChunkGrowthLog2 = 2;
+// (kCutoffOpticalDepth, kChunkOpticalDepths, kMinFirstChunk — a chunk's fixed cost is worth a few hundred thousand
+// instances — and kChunkGrowthLog2 live in gsr_internal.h: the plan is made in gsr_select.hip.)
 
 GeomWS carve_geom(void *base, int P)
 {
@@ -54,7 +53,7 @@ GeomWS carve_geom(void *base, int P)
     w.clamped = (uint8_t *)(b + o); o += align_up(Pn);
     for (int i = 0; i < 2; ++i) { w.sort_keys[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
     for (int i = 0; i < 2; ++i) { w.sort_vals[i] = (uint32_t *)(b + o); o += align_up(Pn * 4); }
-    w.order = w.sort_vals[0];                    // 4 passes of 8 bits: the result lands back in buffer 0
+    w.order = w.sort_vals[0];
     w.offs_full = (uint32_t *)(b + o); o += align_up(Pn * 4);
     w.cnt_open = (uint32_t *)(b + o); o += align_up(Pn * 4);
     w.offs_open = (uint32_t *)(b + o); o += align_up(Pn * 4);
