@@ -308,11 +308,41 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
     plan->binning_initialised = 0;                  // a re-run of this stage must reset the tile ranges / open flags itself
     int sort_result = 0;
     uint64_t emitted_before = 0;                    // instances earlier chunks emitted (exact: read back with the open-tile count)
-    uint32_t open_now = 0xFFFFFFFFu;                // tiles still open before the current chunk (known from chunk 1 on)
+    uint32_t open_now = 0xFFFFFFFFu, stuck_now = 0; // tiles still open before the current chunk, and those nothing covers yet (known from chunk 1 on)
     constexpr int kLiveFilterMin = 1 << 16;         // the filter's launches pay off from this many Gaussians on
     // Early stop: one control-block readback per chunk (~10 us of stream idle, measured); the chunk plan keeps
     // the number of chunks at three or fewer.
     for (int c = 0; c < plan->num_chunks; ++c) {
+        // A frame that is not going to close (an uncovered corner: some open tile still has a pixel that nothing has covered after
+        // the chunks so far, k_render_fwd marks those): every further chunk costs its fixed ~250 us for little.  All remaining chunks then become ONE, which goes
+        // through the live filter below (its Gaussians' relative keys are re-based there).
+        LiveParts parts{1, {0}, {0}};
+        const long long slab_tiles_now = (long long)(f.ty1 - f.ty0) * f.Gx;
+        if (c > 0 && c >= plan->chunks_sorted && c < plan->num_chunks - 1 && stuck_now > 0 && (long long)open_now * 2 < slab_tiles_now &&
+            !getenv("GSR_NO_LIVE_FILTER") && !getenv("GSR_NO_CHUNK_MERGE")) {
+            const int last_c = plan->num_chunks - 1;
+            uint64_t m_max = 0;
+            for (int j = c; j <= last_c; ++j) m_max += (uint64_t)plan->chunk_instances_max[j];
+            const uint64_t m_n = (uint64_t)(plan->chunk_rank_begin[last_c + 1] - plan->chunk_rank_begin[c]);
+            if (m_n >= (uint64_t)kLiveFilterMin && m_max / 32 + 2 * m_n + 4 <= m_max && m_max <= 0xFFFFFFFFull) {
+                if (emitted_before + m_max > (uint64_t)capacity) {          // (before the plan is touched: the re-run decides the same)
+                    set_error("binning workspace holds %lld instances, the remaining depth chunks may need %llu: re-run "
+                              "gsr_forward_render with binning_capacity = num_rendered (%lld)", (long long)capacity,
+                              (unsigned long long)(emitted_before + m_max), (long long)plan->num_rendered);
+                    return GSR_ERR_WORKSPACE;
+                }
+                auto base_of = [&](int j) { const uint32_t e = plan->chunk_key_end[j - 1]; return e < 0x3E4CCCCDu ? 0x3E4CCCCDu : e; };
+                parts.n = last_c - c + 1;
+                for (int j = c; j <= last_c; ++j) {
+                    parts.end[j - c] = (uint32_t)(plan->chunk_rank_begin[j + 1] - plan->chunk_rank_begin[c]);
+                    parts.delta[j - c] = base_of(j) - base_of(c);
+                }
+                plan->chunk_rank_begin[c + 1] = plan->chunk_rank_begin[last_c + 1];
+                plan->chunk_key_end[c] = plan->chunk_key_end[last_c];
+                plan->chunk_instances_max[c] = (int64_t)m_max;
+                plan->num_chunks = c + 1;
+            }
+        }
         const bool last = c == plan->num_chunks - 1;
         const int r0 = plan->chunk_rank_begin[c], r1 = plan->chunk_rank_begin[c + 1];
         if (emitted_before + (uint64_t)plan->chunk_instances_max[c] > (uint64_t)capacity) {
@@ -331,7 +361,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
                               chunk_max / 32 + 2 * chunk_n + 4 <= chunk_max && !getenv("GSR_NO_LIVE_FILTER");
         if (filtered) plan->chunks_filtered |= 1 << c;
         if (c >= plan->chunks_sorted) {
-            if (filtered && (rc = launch_live_filter(f, c, r0, r1, gw, iw, dbg, s))) return rc;
+            if (filtered && (rc = launch_live_filter(f, c, r0, r1, parts, gw, iw, dbg, s))) return rc;
             if ((rc = launch_chunk_order(f, r0, r1, c > 0 ? plan->chunk_key_end[c - 1] : 0u, plan->chunk_key_end[c], c == 0, gw, dbg, s,
                                          filtered ? &gw.ctrl->chunk_live[c] : nullptr)))
                 return rc;
@@ -351,6 +381,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         plan->instances_emitted = (int64_t)h.chunk_base[c + 1];
         emitted_before = (uint64_t)h.chunk_base[c + 1];
         open_now = h.open_count;
+        stuck_now = h.open_stuck;
         if (h.open_count == 0) break;
     }
     plan->sort_result = sort_result;

@@ -104,12 +104,12 @@ constexpr int kBinBlock = 256;
 __global__ __launch_bounds__(1024) void k_open_count(FrameK f, int init, uint32_t *__restrict__ open,
                                                      unsigned long long *__restrict__ open_bits, Ctrl *ctrl)
 {
-    __shared__ uint32_t sh_count;
-    if (threadIdx.x == 0) sh_count = 0;
+    __shared__ uint32_t sh_count, sh_stuck;
+    if (threadIdx.x == 0) { sh_count = 0; sh_stuck = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const int W64 = (f.Gx + 63) >> 6;
-    uint32_t mine = 0;
+    uint32_t mine = 0, stuck = 0;
     for (int j = wave; j < f.Gy * W64; j += n_waves) {        // one wave per (tile row, 64-tile word)
         const int ty = j / W64, tx = (j - ty * W64) * 64 + lane;
         uint32_t o = 0;
@@ -118,12 +118,13 @@ __global__ __launch_bounds__(1024) void k_open_count(FrameK f, int init, uint32_
             if (init) { o = (ty >= f.ty0 && ty < f.ty1) ? 1u : 0u; open[t] = o; }
             else o = open[t];
         }
-        const unsigned long long m = __ballot(o != 0u);
-        if (lane == 0) { open_bits[j] = m; mine += (uint32_t)__popcll(m); }
+        const unsigned long long m = __ballot(o != 0u), m2 = __ballot(o == 2u);
+        if (lane == 0) { open_bits[j] = m; mine += (uint32_t)__popcll(m); stuck += (uint32_t)__popcll(m2); }
     }
     if (lane == 0 && mine) atomicAdd(&sh_count, mine);
+    if (lane == 0 && stuck) atomicAdd(&sh_stuck, stuck);
     __syncthreads();
-    if (threadIdx.x == 0) ctrl->open_count = sh_count;
+    if (threadIdx.x == 0) { ctrl->open_count = sh_count; ctrl->open_stuck = sh_stuck; }
 }
 
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(kLiveThreads) void k_live_scatter(int c, int r0, in
                                                                const uint32_t *__restrict__ pos_key, const uint32_t *__restrict__ pos_tiles,
                                                                const uint8_t *__restrict__ flags, const SelState *__restrict__ st, Ctrl *ctrl,
                                                                uint32_t *__restrict__ t_order, uint32_t *__restrict__ t_key,
-                                                               uint32_t *__restrict__ t_tiles)
+                                                               uint32_t *__restrict__ t_tiles, LiveParts parts)
 {
     __shared__ uint32_t sh_w[2][kLiveWaves], sh_pre[2][kLiveWaves], sh_run[2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -723,7 +724,9 @@ __global__ __launch_bounds__(kLiveThreads) void k_live_scatter(int c, int r0, in
         __syncthreads();
         if (valid) {
             const uint32_t pos = live ? sh_pre[0][wv] + (uint32_t)__popcll(m & below) : sh_pre[1][wv] + (uint32_t)__popcll(mv & ~m & below);
-            t_order[pos] = order[r0 + i]; t_key[pos] = pos_key[r0 + i]; t_tiles[pos] = pos_tiles[r0 + i];
+            uint32_t delta = 0;                                  // (a range merged from several planned chunks: one key base for all)
+            for (int j = 0; j + 1 < parts.n; ++j) delta = (uint32_t)i >= parts.end[j] ? parts.delta[j + 1] : delta;
+            t_order[pos] = order[r0 + i]; t_key[pos] = pos_key[r0 + i] + delta; t_tiles[pos] = pos_tiles[r0 + i];
         }
         live_before = sh_run[0]; dead_before = sh_run[1] - live_total;
     }
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(256) void k_live_copyback(int n, const uint32_t *__
     order[i] = t_order[i]; pos_key[i] = t_key[i]; pos_tiles[i] = t_tiles[i];
 }
 
-int launch_live_filter(const FrameK &f, int c, int r0, int r1, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
+int launch_live_filter(const FrameK &f, int c, int r0, int r1, const LiveParts &parts, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
 {
     const int n = r1 - r0;
     if (n <= 0) return GSR_OK;
@@ -750,7 +753,7 @@ int launch_live_filter(const FrameK &f, int c, int r0, int r1, GeomWS &gw, Image
     uint8_t *flags = reinterpret_cast<uint8_t *>(gw.offs_full + r0);          // n bytes of the chunk's (not yet written) tile-count scan
     hipLaunchKernelGGL(k_live_flags, dim3(blocks), dim3(kLiveThreads), 0, s, f, r0, n, gw.order, gw.records, iw.open_bits, gw.sel, flags);
     hipLaunchKernelGGL(k_live_scatter, dim3(blocks), dim3(kLiveThreads), 0, s, c, r0, n, gw.order, gw.sort_keys[1], gw.sort_vals[1], flags,
-                       gw.sel, gw.ctrl, t_order, t_key, t_tiles);
+                       gw.sel, gw.ctrl, t_order, t_key, t_tiles, parts);
     hipLaunchKernelGGL(k_live_copyback, dim3((n + 255) / 256), dim3(256), 0, s, n, t_order, t_key, t_tiles, gw.order + r0, gw.sort_keys[1] + r0,
                        gw.sort_vals[1] + r0);
     GSR_LAUNCH_CHECK("live_filter", debug, s);

@@ -101,6 +101,7 @@ struct Ctrl {                   // small device-side control block of one frame
     uint32_t chunk_base[GSR_MAX_CHUNKS + 1];   // first absolute instance index of the chunk
     uint32_t chunk_live[GSR_MAX_CHUNKS];       // Gaussians at the front of the chunk's range that can still reach an open tile
                                                // (0xFFFFFFFF: the chunk was not filtered, all of them)
+    uint32_t open_stuck;                       // open tiles with a pixel that is still more than half transparent (nothing covers it yet)
     uint32_t overflow;                         // 1 = the sum of tiles touched does not fit 32 bits
     uint32_t prefilter_violation;              // 1 = prefiltered was set and a Gaussian failed the frustum test (A.1)
 };
@@ -171,7 +172,9 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
 int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_t key_hi, bool first, GeomWS &ws, bool debug, hipStream_t s,
                        const uint32_t *live_count = nullptr);
-int launch_live_filter(const FrameK &f, int c, int r0, int r1, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
+// parts: the range may span several planned chunks (merged by the caller); their relative keys are re-based to the first one's
+struct LiveParts { int n; uint32_t end[GSR_MAX_CHUNKS]; uint32_t delta[GSR_MAX_CHUNKS]; };      // end: position in the range; delta: added to the key
+int launch_live_filter(const FrameK &f, int c, int r0, int r1, const LiveParts &parts, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
 int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, int num_visible, GeomWS &ws,
                         bool debug, hipStream_t s);

@@ -283,7 +283,11 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     store_px(1, P0.Tf[1], P0.Tl[1], P0.Cr[1], P0.Cg[1], P0.Cb[1], P0.last1);
     store_px(2, P1.Tf[0], P1.Tl[0], P1.Cr[0], P1.Cg[0], P1.Cb[0], P1.last0);
     store_px(3, P1.Tf[1], P1.Tl[1], P1.Cr[1], P1.Cg[1], P1.Cb[1], P1.last1);
-    if (lane == 0) open[tile] = closing ? 0u : 1u;
+    // 2 = open AND some pixel is still more than half transparent after everything so far: a tile no splat has covered yet
+    // (the chunk plan merges the remaining chunks when such tiles exist: the frame is not going to close, gsr_api.hip)
+    auto clear_px = [&](int k, float tl) { return px0 + (k & 1) * 8 < f.W && py0 + (k >> 1) * 8 < f.H && tl > 0.5f; };
+    const bool stuck = __ballot(clear_px(0, P0.Tl[0]) || clear_px(1, P0.Tl[1]) || clear_px(2, P1.Tl[0]) || clear_px(3, P1.Tl[1])) != 0ull;
+    if (lane == 0) open[tile] = closing ? 0u : (stuck ? 2u : 1u);
 }
 
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
