@@ -818,7 +818,7 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     uint32_t *wprefix = scratch + 8 * (size_t)n;
     const int tile_bits = msb_plus1((uint32_t)(Tn ? Tn - 1 : 0));
     // a filtered chunk: a fixed grid walks the live front part; everybody else's count is zero from the start
-    const int team_grid = filtered ? (n < 16384 ? n : 16384) : n;
+    const int team_grid = filtered ? (n < 65536 ? n : 65536) : n;      // (4 k: +35 us per launch, 256 k: +20 us; measured)
     if (filtered) GSR_HIP_CHECK(hipMemsetAsync(gw.cnt_open + r0, 0, (size_t)n * sizeof(uint32_t), s));
     {
         ProfileScope prof("count_open", s);
