@@ -475,12 +475,37 @@ __global__ __launch_bounds__(kBinBlock) void k_bin_chunk(FrameK f, int c, int r0
 // accept it" (one bit of the rank's mask words) and append the accepted ranks to the tile's list in rank order =
 // depth order.  The result is bit for bit what emit + stable sort + ranges produce; the work is ranks x open tiles
 // bit tests (44 M for cfg3's first chunk) instead of a 2 M-key radix sort.
-__global__ __launch_bounds__(1024) void k_tile_ranges(FrameK f, int c, const Ctrl *__restrict__ ctrl, uint32_t *__restrict__ tile_cnt,
-                                                      uint2 *__restrict__ ranges_c)
+// scan_n > 0 (chunks of up to kRankScanMax Gaussians): the same block first scans the chunk's per-rank counts (offs_open, the chunk's
+// emitted total and the next chunk's base), which saves the launch of a one-block scan in front of this one.
+constexpr int kRankScanMax = 16384;
+__global__ __launch_bounds__(1024) void k_tile_ranges(FrameK f, int c, Ctrl *__restrict__ ctrl, uint32_t *__restrict__ tile_cnt,
+                                                      uint2 *__restrict__ ranges_c, int scan_n, const uint32_t *__restrict__ cnt_open,
+                                                      uint32_t *__restrict__ offs_open)
 {
     __shared__ uint32_t sh_wave[16];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int t_begin = f.ty0 * f.Gx, t_end = f.ty1 * f.Gx;
+    if (scan_n > 0) {
+        constexpr int kPer = kRankScanMax / 1024;                // 16 consecutive ranks per thread
+        uint32_t v[kPer], mine = 0;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) { const int r = (int)threadIdx.x * kPer + i; v[i] = r < scan_n ? cnt_open[r] : 0u; mine += v[i]; }
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t u = __shfl_up(inc, off);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) sh_wave[wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - mine, total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const uint32_t u = sh_wave[i]; if (i < wv) run += u; total += u; }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) { const int r = (int)threadIdx.x * kPer + i; run += v[i]; if (r < scan_n) offs_open[r] = run; }
+        if (threadIdx.x == 0) { ctrl->chunk_R[c] = total; ctrl->chunk_base[c + 1] = ctrl->chunk_base[c] + total; }
+        __syncthreads();
+    }
     uint32_t carry = ctrl->chunk_base[c];
     for (int t0 = t_begin; t0 < t_end; t0 += 1024) {
         const int t = t0 + (int)threadIdx.x;
@@ -834,8 +859,9 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
 #undef GSR_CT
         GSR_LAUNCH_CHECK("count_open", debug, s);
     }
-    if ((rc = launch_scan_inclusive(gw.cnt_open + r0, gw.offs_open + r0, n, gw.scan_temp, &gw.ctrl->chunk_R[c],
-                                    &gw.ctrl->chunk_base[c], &gw.ctrl->chunk_base[c + 1], "scan_open", debug, s)))
+    const bool fused_scan = gather && n <= kRankScanMax;         // the rank scan rides in k_tile_ranges
+    if (!fused_scan && (rc = launch_scan_inclusive(gw.cnt_open + r0, gw.offs_open + r0, n, gw.scan_temp, &gw.ctrl->chunk_R[c],
+                                                   &gw.ctrl->chunk_base[c], &gw.ctrl->chunk_base[c + 1], "scan_open", debug, s)))
         return rc;
     if (gather) {
         // the list ends where the radix passes would have left it, so that all chunks of a frame agree on the buffer
@@ -843,7 +869,8 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
         *sort_result = res;
         {
             ProfileScope prof("tile_ranges", s);
-            hipLaunchKernelGGL(k_tile_ranges, dim3(1), dim3(1024), 0, s, f, c, gw.ctrl, iw.tile_cnt, iw.ranges + (size_t)c * Tn);
+            hipLaunchKernelGGL(k_tile_ranges, dim3(1), dim3(1024), 0, s, f, c, gw.ctrl, iw.tile_cnt, iw.ranges + (size_t)c * Tn,
+                               fused_scan ? n : 0, gw.cnt_open + r0, gw.offs_open + r0);
             GSR_LAUNCH_CHECK("tile_ranges", debug, s);
         }
         ProfileScope prof("tile_gather", s);
