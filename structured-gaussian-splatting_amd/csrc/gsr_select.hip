@@ -366,28 +366,34 @@ int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
 //
 // Small chunks (the nearest chunk of a saturating frame: 5 K Gaussians at cfg3) are sorted by ONE block in LDS.  One CU
 // issues about one wave instruction per SIMD every four cycles, so instructions are what counts: the keys are dealt into
-// 2048 buckets by their top bits (one LDS atomic each), the bucket sizes are scanned, and every thread insertion-sorts its
-// two buckets (2.6 keys on average at cfg3) by (key, position in the partition = Gaussian index order).  The result does
-// not depend on the order the atomics landed in.  Keys that crowd into one bucket (> kBucketMax) would make a thread's
-// insertion sort quadratic: that chunk takes the 4-bit radix passes below instead (stable, any distribution, ~8x slower).
-constexpr int kSmallSortMax = 8192;
-constexpr int kSmallThreads = 1024;
-constexpr int kSmallPer = kSmallSortMax / kSmallThreads;      // 8 keys per thread
-constexpr int kBuckets = 2048;
+// 4096 buckets by their top bits (one LDS atomic each), the bucket sizes are scanned, and the keys are rank-sorted inside their
+// buckets (1.3 keys per bucket on average at cfg3, 3.8 at cfg2's 15 k) by (key, position in the partition = Gaussian index
+// order).  The result does not depend on the order the atomics landed in.  Keys that crowd into one bucket (> kBucketMax:
+// equal depths) take the 4-bit radix passes below instead (stable, any distribution, ~8x slower).
+constexpr int kSmallSortMax = 16384;                          // two instantiations: 8192 keys (8 per thread) and 16384 (16 per thread,
+constexpr int kSmallThreads = 1024;                           // some of them spilled: only chunks that need it take that one)
+constexpr int kBuckets = 4096;
+constexpr int kBucketsPer = kBuckets / kSmallThreads;
+constexpr int kBucketBits = 12;
 constexpr int kBucketMax = 32;
-constexpr int kSmallGroups = kSmallSortMax / kWave;           // radix fallback: 128 groups of 64 keys
-constexpr int kSmallPerWave = kSmallGroups / (kSmallThreads / kWave);
 
+template <int CAP>
 __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint32_t r0, int bits, int force_radix,
                                                                     const uint32_t *__restrict__ pos_key,
                                                                     const uint32_t *__restrict__ pos_tiles, uint32_t *__restrict__ order,
                                                                     uint32_t *__restrict__ offs_full)
 {
-    __shared__ unsigned long long sc[kSmallSortMax];             // fast path: (relative key << 32 | original slot) by bucket order
-    uint32_t *sk = reinterpret_cast<uint32_t *>(sc), *sv = sk + kSmallSortMax;    // fallback: the same memory as two arrays
-    __shared__ uint32_t sg[kSmallSortMax], st[kSmallSortMax];    // by original slot: Gaussian, tiles touched
-    __shared__ uint32_t bcnt[kBuckets], bofs[kBuckets];
-    __shared__ unsigned short cnt[16 * kSmallGroups];            // radix fallback: [digit][group]
+    constexpr int kSmallPer = CAP / kSmallThreads;               // keys per thread
+    constexpr int kSmallGroups = CAP / kWave;                    // groups of 64 keys
+    constexpr int kSmallPerWave = kSmallGroups / (kSmallThreads / kWave);
+    constexpr int kSmallCntPer = 16 * kSmallGroups / kSmallThreads;      // radix fallback: counters per thread in its scan
+    __shared__ unsigned long long sc[CAP];                       // fast path: (relative key << 32 | original slot) by bucket order
+    uint32_t *sk = reinterpret_cast<uint32_t *>(sc), *sv = sk + CAP;      // fallback: the same memory as two arrays
+    constexpr bool kStage = CAP <= 8192;                         // room to keep (Gaussian, tiles) by original slot in LDS
+    __shared__ uint32_t sg[kStage ? CAP : 1], st[kStage ? CAP : 1];
+    __shared__ uint32_t bcnt[kBuckets];
+    __shared__ unsigned short bofs[kBuckets];
+    unsigned short *cnt = reinterpret_cast<unsigned short *>(bcnt);      // radix fallback: [digit][group], over the bucket counters
     __shared__ uint32_t sh_wave[kSmallThreads / kWave];
     __shared__ uint32_t sh_max;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -398,10 +404,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
     for (int j = 0; j < kSmallPer; ++j) {                        // coalesced: the partition left keys and tile counts by position
         const int e = threadIdx.x + j * kSmallThreads;
         key[j] = 0xFFFFFFFFu; bkt[j] = 0; slot[j] = 0;
-        if (e < n) { key[j] = pos_key[r0 + e]; sg[e] = order[r0 + e]; st[e] = pos_tiles[r0 + e]; }
+        if (e < n) {
+            key[j] = pos_key[r0 + e];
+            if constexpr (kStage) { sg[e] = order[r0 + e]; st[e] = pos_tiles[r0 + e]; }
+        }
     }
     __syncthreads();
-    const int bshift = bits > 11 ? bits - 11 : 0;
+    const int bshift = bits > kBucketBits ? bits - kBucketBits : 0;
 #pragma unroll
     for (int j = 0; j < kSmallPer; ++j) {
         const int e = threadIdx.x + j * kSmallThreads;
@@ -412,9 +421,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
         }
     }
     __syncthreads();
-    {   // exclusive scan of the bucket sizes (2 per thread) and their maximum
-        const uint32_t c0 = bcnt[2 * threadIdx.x], c1 = bcnt[2 * threadIdx.x + 1], mine = c0 + c1;
-        uint32_t inc = mine, mx = c0 > c1 ? c0 : c1;
+    {   // exclusive scan of the bucket sizes (4 per thread) and their maximum
+        uint32_t c[kBucketsPer], mine = 0, mx = 0;
+#pragma unroll
+        for (int i = 0; i < kBucketsPer; ++i) { c[i] = bcnt[kBucketsPer * threadIdx.x + i]; mine += c[i]; mx = c[i] > mx ? c[i] : mx; }
+        uint32_t inc = mine;
 #pragma unroll
         for (int off = 1; off < kWave; off <<= 1) {
             const uint32_t u = (uint32_t)__shfl_up((int)inc, off);
@@ -427,7 +438,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
         __syncthreads();
         uint32_t run = inc - mine;
         for (int i = 0; i < wv; ++i) run += sh_wave[i];
-        bofs[2 * threadIdx.x] = run; bofs[2 * threadIdx.x + 1] = run + c0;
+#pragma unroll
+        for (int i = 0; i < kBucketsPer; ++i) { bofs[kBucketsPer * threadIdx.x + i] = (unsigned short)run; run += c[i]; }
     }
     __syncthreads();
     const bool fast = sh_max <= (uint32_t)kBucketMax;             // block-uniform
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
 #pragma unroll
         for (int j = 0; j < kSmallPer; ++j) {
             const int e = threadIdx.x + j * kSmallThreads;
-            if (e < n) sc[bofs[bkt[j]] + slot[j]] = ((unsigned long long)key[j] << 32) | (unsigned long long)e;
+            if (e < n) sc[(uint32_t)bofs[bkt[j]] + slot[j]] = ((unsigned long long)key[j] << 32) | (unsigned long long)e;
         }
         __syncthreads();
         // RANK sort inside the buckets, one position per lane: a position's bucket spans at most kBucketMax neighbours on
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int q = p + d + u;
-                        nb[u] = sc[q < 0 ? 0 : (q >= kSmallSortMax ? kSmallSortMax - 1 : q)];
+                        nb[u] = sc[q < 0 ? 0 : (q >= CAP ? CAP - 1 : q)];
                     }
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
@@ -513,8 +525,10 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
                 }
             }
             __syncthreads();
-            {   // exclusive scan of the 2048 counters in [digit][group] order, 2 per thread
-                const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1], mine = c0 + c1;
+            {   // exclusive scan of the 4096 counters in [digit][group] order, 4 per thread
+                uint32_t c[kSmallCntPer], mine = 0;
+#pragma unroll
+                for (int i = 0; i < kSmallCntPer; ++i) { c[i] = cnt[kSmallCntPer * threadIdx.x + i]; mine += c[i]; }
                 uint32_t inc = mine;
 #pragma unroll
                 for (int off = 1; off < kWave; off <<= 1) {
@@ -525,7 +539,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
                 __syncthreads();
                 uint32_t run = inc - mine;
                 for (int i = 0; i < wv; ++i) run += sh_wave[i];
-                cnt[2 * threadIdx.x] = (unsigned short)run; cnt[2 * threadIdx.x + 1] = (unsigned short)(run + c0);
+#pragma unroll
+                for (int i = 0; i < kSmallCntPer; ++i) { cnt[kSmallCntPer * threadIdx.x + i] = (unsigned short)run; run += c[i]; }
             }
             __syncthreads();
 #pragma unroll
@@ -539,14 +554,25 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
             __syncthreads();
         }
     }
-    // the chunk in depth order + the inclusive scan of its tile counts (8 consecutive ranks per thread)
-    uint32_t t[kSmallPer], sum = 0;
+    // the chunk in depth order + the inclusive scan of its tile counts (16 consecutive ranks per thread): Gaussian and tile
+    // count come from where the partition left them (by original slot); all reads before the first write
+    uint32_t t[kSmallPer], gs[kSmallPer], sum = 0;
 #pragma unroll
     for (int i = 0; i < kSmallPer; ++i) {
         const int e = threadIdx.x * kSmallPer + i;
-        t[i] = 0;
-        if (e < n) { const uint32_t src = sorted_slot[e]; order[r0 + e] = sg[src]; t[i] = st[src]; }
+        t[i] = 0; gs[i] = 0;
+        if (e < n) {
+            const uint32_t src = sorted_slot[e];
+            if constexpr (kStage) { gs[i] = sg[src]; t[i] = st[src]; }
+            else { gs[i] = order[r0 + src]; t[i] = pos_tiles[r0 + src]; }
+        }
         sum += t[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kSmallPer; ++i) {
+        const int e = threadIdx.x * kSmallPer + i;
+        if (e < n) order[r0 + e] = gs[i];
     }
     uint32_t inc = sum;
 #pragma unroll
@@ -589,8 +615,12 @@ int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_
     if (n <= kSmallSortMax && !live_count) {
         const int force_radix = getenv("GSR_SORT_FORCE_RADIX") ? 1 : 0;               // test hook: the fallback path of the LDS sort
         ProfileScope prof("chunk_sort", s);
-        hipLaunchKernelGGL(k_chunk_sort_small, dim3(1), dim3(kSmallThreads), 0, s, n, (uint32_t)r0, bits, force_radix, ws.sort_keys[1],
-                           ws.sort_vals[1], ws.order, ws.offs_full);
+        if (n <= kSmallSortMax / 2)
+            hipLaunchKernelGGL(k_chunk_sort_small<kSmallSortMax / 2>, dim3(1), dim3(kSmallThreads), 0, s, n, (uint32_t)r0, bits, force_radix,
+                               ws.sort_keys[1], ws.sort_vals[1], ws.order, ws.offs_full);
+        else
+            hipLaunchKernelGGL(k_chunk_sort_small<kSmallSortMax>, dim3(1), dim3(kSmallThreads), 0, s, n, (uint32_t)r0, bits, force_radix,
+                               ws.sort_keys[1], ws.sort_vals[1], ws.order, ws.offs_full);
         GSR_LAUNCH_CHECK("chunk_sort", debug, s);
         return GSR_OK;
     }
