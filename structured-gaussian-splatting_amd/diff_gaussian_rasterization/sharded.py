@@ -126,6 +126,7 @@ class _Comm:
         self.dist, self.world, self.rank, self.group = dist, world, rank, group
         self.gloo = dist.get_backend(group) == "gloo"      # tests only: device tensors are staged through the host
         self.native_rs = not self.gloo
+        self._pinned, self._pinned_turn = {}, 0
 
     def all_gather(self, shard: torch.Tensor) -> torch.Tensor:
         """[n, ...] per rank -> [world * n, ...]."""
@@ -158,7 +159,14 @@ class _Comm:
         if halves.device.type != "cuda":
             v = pick(halves.tolist())
             return lambda: v
-        host = torch.empty(halves.shape, dtype=halves.dtype).pin_memory()
+        # (pinned buffers are recycled: pin_memory() is a host allocation of tens of microseconds; two in rotation, a frame's
+        # backward reads its buffer before the next-but-one forward overwrites it)
+        key = (tuple(halves.shape), halves.dtype)
+        ring = self._pinned.setdefault(key, [])
+        if len(ring) < 2:
+            ring.append(torch.empty(halves.shape, dtype=halves.dtype).pin_memory())
+        host = ring[self._pinned_turn % len(ring)] if len(ring) == 2 else ring[-1]
+        self._pinned_turn += 1
         host.copy_(halves, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(halves.device))
@@ -220,7 +228,7 @@ class _ShardedRasterize(torch.autograd.Function):
         want_prefix = shard.backward_mode == "allreduce_screen" and any(needs) and caller_grad_enabled()
         keys, k_mine, n_mine = backend.binned_prefix(frame) if want_prefix else (None, -1, 0)
         for j, v in enumerate(((int(k_mine) + 1) >> 16, (int(k_mine) + 1) & 0xFFFF, int(n_mine) >> 16, int(n_mine) & 0xFFFF)):
-            mine[0, n_words + j].fill_(float(v))
+            mine[0, n_words + j].fill_(float(v))            # (fills, not an H2D copy of a host tensor: that one waits for the stream)
         if balance:          # this rank's per-tile-row work rides along; the sum over ranks is next frames' slab weights
             mine[0, n_words + 4:] = backend.row_work(frame, (W + 15) // 16, Gy).to(mine.dtype)
         gathered = comm.all_gather(mine)                        # [world, 3 * rows_max * W + 4 (+ Gy)]
@@ -239,6 +247,12 @@ class _ShardedRasterize(torch.autograd.Function):
             hook = getattr(backend, "prepare_backward", None)       # the native provider zero-fills the backward's outputs now
             if hook is not None:
                 hook(frame, needs)
+            # ... and the host picks the pair up HERE, behind the copies and the fill it has just enqueued (the stream is busy for
+            # another ~50 us): waiting for it in the backward stalled the host until the whole forward + loss had drained, and every
+            # launch of the backward then arrived late (0.39 ms of idle stream per step at world size 1).
+            if ctx.n_max[1] is not None:
+                pair = ctx.n_max[1]()
+                ctx.n_max = (keys, lambda: pair)
         ctx.shapes = (means2D.shape, opacities.shape)
         ctx.mark_non_differentiable(radii)
         return full, radii
