@@ -1251,3 +1251,29 @@ def test_frame_with_an_uncovered_region_runs_the_live_filter_and_matches_the_ora
     gimg = S.make_grad_image(W, H, 4).numpy()
     *_, live = _forward_backward_strict(kw, fr64, gimg, label="uncovered half", parallel=True)
     assert live > 1000
+
+
+def test_one_call_forward_falls_back_when_the_guessed_workspace_is_too_small():
+    """rasterize_forward brings a binning workspace guessed from the last frame of the same shape and runs both stages in one
+    native call (gsr_forward).  A guess that does not cover the first chunk (the scene grew) makes that call answer
+    GSR_ERR_WORKSPACE after stage 1, nothing of stage 2 enqueued: the two-call path takes over and the frame equals a frame
+    rendered without any guess, bit for bit — image, radii and screen-space gradients."""
+    import diff_gaussian_rasterization as dgr
+    kw = _fixture_kwargs(dict(P=5000, W=256, H=192, D=3, seed=109))
+    rs, inp = _settings(kw), _inputs(kw, False)
+    args = (inp["means3D"], inp["shs"], None, inp["opacities"], inp["scales"], inp["rotations"], None, rs)
+    gimg = S.make_grad_image(256, 192, 9).to(DEV)
+    dgr._binning_guess.clear()
+    c0, r0, f0 = dgr.rasterize_forward(*args)                     # no guess: preprocess, then render
+    s0 = dgr.rasterize_backward_screen(f0, gimg).clone()
+    key = next(iter(dgr._binning_guess))
+    assert dgr._binning_guess[key] >= int(f0.plan.chunk_instances_max[0])
+    c1, r1, f1 = dgr.rasterize_forward(*args)                     # good guess: one call
+    s1 = dgr.rasterize_backward_screen(f1, gimg).clone()
+    dgr._binning_guess[key] = 7                                   # hopeless guess: one call gives up, two-call path finishes
+    c2, r2, f2 = dgr.rasterize_forward(*args)
+    s2 = dgr.rasterize_backward_screen(f2, gimg)
+    assert dgr._binning_guess[key] >= int(f2.plan.chunk_instances_max[0])
+    for c, r, s_ in ((c1, r1, s1), (c2, r2, s2)):
+        assert torch.equal(c, c0) and torch.equal(r, r0) and torch.equal(s_, s0)
+    dgr._binning_guess.clear()
