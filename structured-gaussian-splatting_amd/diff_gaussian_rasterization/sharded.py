@@ -397,11 +397,7 @@ class ShardedRenderer:
 
         from . import GaussianRasterizationSettings
         xyz = pc.get_xyz
-        screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
-        try:
-            screenspace_points.retain_grad()
-        except Exception:
-            pass
+        screenspace_points = torch.zeros_like(xyz, requires_grad=True)     # a leaf keeps its .grad (gaussian_renderer.render)
         rs = GaussianRasterizationSettings(
             image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
             tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,

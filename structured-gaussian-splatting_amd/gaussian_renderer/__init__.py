@@ -45,11 +45,9 @@ def eval_sh(deg: int, sh: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene.  Background tensor (bg_color) must be on the GPU."""
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # (the reference builds this as zeros_like(...) + 0 and retain_grad()s the non-leaf result; a leaf with requires_grad keeps
+    # its .grad by itself and costs one fill instead of a fill and an add over P x 3)
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
