@@ -74,7 +74,8 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
         "reduce_rows": 36 * Re + 36 * Vb,                   # deterministic reduction (replaces atomic RMW)
         "geom_bwd": 4 * geom_rows + (99 + 12 * K) * Vlive + (40 + 12 * M) * geom_written,        # K8 + K9
         "loss_fwd": 20 * C * N, "loss_bwd": 24 * C * N,
-        "zero_outputs": (104 + 12 * M) * P if prezeroed else 0,      # early fill: screen-space (48 B) + parameter gradients
+        "zero_outputs": (56 + 12 * M) * P if prezeroed else 0,       # early fill of the parameter gradients (means3D, means2D, opacity,
+                                                                      # scales, rotations, SH); the screen-space tensor is never cleared
     }
 
 
@@ -316,6 +317,9 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
         keys = {"chunk_sort": Vb, "tile_sort": Re}.get(k)            # SURVEY 8d secondary rate for K4: keys/s
         if keys is not None and per_step_ms > 0:
             per_kernel[k]["Gkeys_per_s"] = keys / 1e9 / (per_step_ms / 1e3)
+    # no kernel may be credited with more algorithmic bytes than the HBM could move in its time (an accounting check: reported,
+    # never raised — the line must always come out)
+    over = sorted(k for k, v in per_kernel.items() if v["alg_GBs"] is not None and v["alg_GBs"] > HBM_PEAK_GBS)
     raster_ms = sum(ms for ms, _ in prof.values()) / steps
     roofline = None
     if prof:
@@ -329,7 +333,7 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=_traffic_from_profiles(dom) if traffic else None,
                         avg_launch_ms=round(dom_ms, 4), algorithmic_bytes_per_launch=int(bytes_per_launch),
-                        step_algorithmic_bytes=int(sum(alg.values())),
+                        step_algorithmic_bytes=int(sum(alg.values())), kernels_over_hbm_peak=over,
                         step_frac=round(sum(alg.values()) / 1e9 / (elapsed / steps) / HBM_PEAK_GBS, 5),
                         # context only: SURVEY 8d's whole-step total evaluated as the REFERENCE's algorithm would move it
                         # (all R = num_rendered duplicates; this design bins `instances_emitted` of them), over the same time

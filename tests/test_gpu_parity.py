@@ -1166,6 +1166,7 @@ def test_bench_line_contract():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and 0 < r["frac"] < 1
     assert r["traffic"] is None                      # PMC traffic is only attached to the run it was measured on (cfg3)
+    assert r["kernels_over_hbm_peak"] == []          # the per-kernel algorithmic-byte table charges nothing twice
     assert d["cpu_baseline"] is None                 # --no-cpu-baseline
 
 
