@@ -100,3 +100,29 @@ def test_python_mirror_of_binning_size_matches_the_library():
         plan.chunk_instances_max[0] = first
         want = min(first + first // 4 + (1 << 20), R) if chunks > 1 else R
         assert N.binning_first_chunk_capacity(plan) == want
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_header(native, tmp_path):
+    """include/gsrast.h is plain C: gcc compiles it, and size + every field offset of each struct equals the ctypes
+    mirror's (the layout a cgo / JNI / ctypes binding of the header would see)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not on PATH")
+    pairs = (("gsr_frame_desc", native.FrameDesc), ("gsr_frame_plan", native.FramePlan), ("gsr_camera", native.Camera),
+             ("gsr_gaussians", native.Gaussians), ("gsr_grads", native.Grads), ("gsr_debug_views", native.DebugViews))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "gsrast.h"', 'int main(void) {']
+    for cname, mirror in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, mirror in pairs:
+        assert int(got[cname]) == C.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(mirror, fname).offset, f"{cname}.{fname}"
