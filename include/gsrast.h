@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 10
+#define GSR_VERSION 11
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -229,6 +229,9 @@ typedef struct gsr_debug_views {
     const uint32_t *ranges;        /* [GSR_MAX_CHUNKS, Tn, 2] absolute [start, end) per chunk and tile   */
     const float *final_T;          /* [H*W] (negative sign marks a pixel that hit the cut-off)           */
     const int32_t *n_contrib;      /* [H*W] encoded: (chunk + 1) << 26 | position in that chunk's range  */
+    const uint32_t *tile_work;     /* [Tn] list entries the blend backward walks per tile (deepest contributor, summed over chunks) */
+    const uint32_t *tile_order;    /* [tiles of the slab] valid after gsr_backward_render: its launch order, slab-relative tile
+                                      indices, longest tile first                                        */
 } gsr_debug_views;
 int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws,
                         const void *image_ws, const gsr_frame_plan *plan_host, gsr_debug_views *views);

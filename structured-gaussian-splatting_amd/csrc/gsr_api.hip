@@ -600,6 +600,7 @@ int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const v
         ImageWS iw = carve_image(const_cast<void *>(image_ws), f);
         v->ranges = reinterpret_cast<const uint32_t *>(iw.ranges);
         v->final_T = iw.T_state; v->n_contrib = iw.last_enc;
+        v->tile_work = iw.tile_work; v->tile_order = iw.tile_order;
     }
     return GSR_OK;
 }

@@ -78,6 +78,8 @@ ImageWS carve_image(void *base, const FrameK &f)
     w.open = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
     w.open_bits = (unsigned long long *)(b + o); o += align_up((size_t)(f.Gy > 0 ? f.Gy : 1) * (size_t)((f.Gx + 63) / 64 + 1) * 8);
     w.ctrl_scratch = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
+    w.tile_work = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
+    w.tile_order = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
     w.total = o;
     return w;
 }

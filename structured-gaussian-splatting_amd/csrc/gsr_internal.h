@@ -132,6 +132,8 @@ struct ImageWS {                // O(N + Tn): the reference's imgBuffer
     uint32_t *tile_cnt;         // [Tn] instances per tile of the chunk being binned (gather variant; zero between chunks)
     uint32_t *open;             // [Tn] 1 = tile still has an unsaturated pixel (0 outside the slab)
     unsigned long long *open_bits;   // [Gy][ceil(Gx/64)] the same flags, one bit per tile (rebuilt at chunk boundaries)
+    uint32_t *tile_work;        // [Tn] list entries the backward will walk per tile (written by K6, summed over the chunks)
+    uint32_t *tile_order;       // [Tn] the slab's tiles (relative index), longest first: launch order of K7
     Ctrl *ctrl_scratch;         // stand-in control block for frames without a geometry workspace (P == 0)
     size_t total;
 };

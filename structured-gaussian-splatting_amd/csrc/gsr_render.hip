@@ -77,6 +77,13 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+__device__ __forceinline__ int wave_max_uniform(int v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 __device__ __forceinline__ float bcast_lane63(float v)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
                                                       const uint32_t *__restrict__ sorted_gid,
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
                                                       float *__restrict__ out_color, float *__restrict__ T_state,
-                                                      int32_t *__restrict__ last_enc)
+                                                      int32_t *__restrict__ last_enc, uint32_t *__restrict__ tile_work)
 {
     __shared__ float4 sh_rec[kWave * 3];
     const int t = xcd_remap(blockIdx.x, n_tiles);
@@ -287,7 +294,13 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     // (the chunk plan merges the remaining chunks when such tiles exist: the frame is not going to close, gsr_api.hip)
     auto clear_px = [&](int k, float tl) { return px0 + (k & 1) * 8 < f.W && py0 + (k >> 1) * 8 < f.H && tl > 0.5f; };
     const bool stuck = __ballot(clear_px(0, P0.Tl[0]) || clear_px(1, P0.Tl[1]) || clear_px(2, P1.Tl[0]) || clear_px(3, P1.Tl[1])) != 0ull;
-    if (lane == 0) open[tile] = closing ? 0u : (stuck ? 2u : 1u);
+    // what the backward's wave will walk of this chunk's range: up to the tile's deepest contributor (launch order of K7)
+    auto depth_here = [&](int last) { return (last >> kLastShift) == c + 1 ? (last & ((1 << kLastShift) - 1)) : 0; };
+    const int walked = wave_max_uniform(max(max(depth_here(P0.last0), depth_here(P0.last1)), max(depth_here(P1.last0), depth_here(P1.last1))));
+    if (lane == 0) {
+        open[tile] = closing ? 0u : (stuck ? 2u : 1u);
+        tile_work[tile] = (c == 0 ? 0u : tile_work[tile]) + (uint32_t)walked;
+    }
 }
 
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
@@ -299,7 +312,7 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
     const size_t Tn = (size_t)f.Gx * f.Gy;
     hipLaunchKernelGGL(k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, c, last_chunk ? 1 : 0,
                        iw.ranges + (size_t)c * Tn, iw.open, bw.sorted_gid, gw.records, cam.bg, out_color, iw.T_state,
-                       iw.last_enc);
+                       iw.last_enc, iw.tile_work);
     GSR_LAUNCH_CHECK("render_fwd", debug, s);
     return GSR_OK;
 }
@@ -397,22 +410,121 @@ __device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &s
     return bwd_pair<3>(sp, lp, dx, dy, pos, P, A);
 }
 
-__device__ __forceinline__ int wave_max_uniform(int v)
+// Launch order of K7: the tiles of the slab by the work the forward measured, longest first.  All of a frame's tiles are
+// resident or queued at once (one wave each, 4 per SIMD) and a wave lives for a third of the kernel, so the launch ends with
+// the SIMDs draining: in tile order that tail was 45 % of the kernel at cfg3 (tools/bwd_trace.py) and the XCDs, which own
+// contiguous bands of tiles, finished up to 60 us apart.  Longest first, dealt round-robin over the XCDs (block b runs on XCD
+// b % 8), evens the XCDs out and leaves the shortest tiles for the end.  One block: counting sort on min(work, 4095),
+// descending.  Tiles of equal work land in the order their atomics did: the order decides which block runs a tile, never a
+// value.
+constexpr int kOrderBins = 4096;
+constexpr int kOrderThreads = 1024;
+constexpr int kOrderPer = 8;                 // tiles a thread keeps in registers (frames up to 8192 tiles: 1080p has 8160)
+__global__ __launch_bounds__(kOrderThreads) void k_tile_order(int n_tiles, int tile_base, const uint32_t *__restrict__ tile_work,
+                                                              uint32_t *__restrict__ tile_order)
 {
+    __shared__ uint32_t hist[kOrderBins];
+    __shared__ uint32_t sh_wave[kOrderThreads / kWave];
+    __shared__ uint32_t sh_max;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < kOrderBins; j += kOrderThreads) hist[j] = 0;
+    if (threadIdx.x == 0) sh_max = 0;
+    uint32_t w[kOrderPer], mx = 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return __builtin_amdgcn_readfirstlane(v);
+    for (int i = 0; i < kOrderPer; ++i) {
+        const int t = threadIdx.x + i * kOrderThreads;
+        w[i] = t < n_tiles ? tile_work[tile_base + t] : 0u;
+        mx = w[i] > mx ? w[i] : mx;
+    }
+    for (int t = threadIdx.x + kOrderPer * kOrderThreads; t < n_tiles; t += kOrderThreads) { const uint32_t v = tile_work[tile_base + t]; mx = v > mx ? v : mx; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)mx, off); mx = u > mx ? u : mx; }
+    __syncthreads();
+    if (lane == 0) atomicMax(&sh_max, mx);
+    __syncthreads();
+    // bin = work scaled to 9 bits (the longest tile -> 511), three low bits from the tile index: equal work spreads over
+    // eight counters instead of queueing on one LDS address
+    int shift = 0;
+    while ((sh_max >> shift) > 511u) ++shift;
+    auto bin_of = [&](uint32_t work, int t) { return (kOrderBins - 1) - (int)(((work >> shift) << 3) | (uint32_t)(7 - (t & 7))); };
+    uint32_t slot[kOrderPer];
+#pragma unroll
+    for (int i = 0; i < kOrderPer; ++i) {
+        const int t = threadIdx.x + i * kOrderThreads;
+        if (t < n_tiles) slot[i] = atomicAdd(&hist[bin_of(w[i], t)], 1u);
+    }
+    __syncthreads();                                   // the register-held tiles own the first slots of their bins
+    for (int t = threadIdx.x + kOrderPer * kOrderThreads; t < n_tiles; t += kOrderThreads) atomicAdd(&hist[bin_of(tile_work[tile_base + t], t)], 1u);
+    __syncthreads();
+    {   // exclusive scan of the 4096 bins, 4 consecutive per thread
+        uint32_t c[4], mine = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c[i] = hist[4 * threadIdx.x + i]; mine += c[i]; }
+        uint32_t inc = mine;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t u = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) sh_wave[wv] = inc;
+        __syncthreads();
+        uint32_t run = inc - mine;
+        for (int i = 0; i < wv; ++i) run += sh_wave[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { hist[4 * threadIdx.x + i] = run; run += c[i]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kOrderPer; ++i) {
+        const int t = threadIdx.x + i * kOrderThreads;
+        if (t < n_tiles) tile_order[hist[bin_of(w[i], t)] + slot[i]] = (uint32_t)t;
+    }
+    // frames of more than 8192 tiles: the rest goes behind its bin's register-held tiles, in the order the atomics land
+    __syncthreads();
+    if (n_tiles > kOrderPer * kOrderThreads) {
+#pragma unroll
+        for (int i = 0; i < kOrderPer; ++i) {           // advance every bin past the slots handed out above
+            const int t = threadIdx.x + i * kOrderThreads;
+            if (t < n_tiles) atomicAdd(&hist[bin_of(w[i], t)], 1u);
+        }
+        __syncthreads();
+        for (int t = threadIdx.x + kOrderPer * kOrderThreads; t < n_tiles; t += kOrderThreads)
+            tile_order[atomicAdd(&hist[bin_of(tile_work[tile_base + t], t)], 1u)] = (uint32_t)t;
+    }
 }
+
+#ifdef GSR_BWD_TRACE
+// debug build only (tools/bwd_trace.py): per block {start, end (100 MHz clock), HW_ID, XCC_ID} of the last launch
+__device__ unsigned long long g_bwd_trace[4 * 65536];
+extern "C" int gsr_debug_bwd_trace(unsigned long long *host_out, int n_blocks)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bwd_trace), sizeof(unsigned long long) * 4 * (size_t)n_blocks);
+}
+#endif
 
 __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
                                                       const uint32_t *__restrict__ sorted_gid,
                                                       const uint32_t *__restrict__ sorted_slot,
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
                                                       const float *__restrict__ T_state, const int32_t *__restrict__ last_enc,
-                                                      const float *__restrict__ dL_dpix, float4 *__restrict__ grad_rows)
+                                                      const float *__restrict__ dL_dpix, float4 *__restrict__ grad_rows,
+                                                      const uint32_t *__restrict__ tile_order)
 {
     __shared__ float4 sh_rec[kWave * 3];
-    const int t = xcd_remap(blockIdx.x, n_tiles);
+#ifdef GSR_BWD_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+    struct TraceEnd {
+        unsigned long long t0; int b;
+        __device__ ~TraceEnd() {
+            if (threadIdx.x == 0 && b < 65536) {
+                g_bwd_trace[4 * b] = t0; g_bwd_trace[4 * b + 1] = wall_clock64();
+                g_bwd_trace[4 * b + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+                g_bwd_trace[4 * b + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+            }
+        }
+    } trace_end{trace_t0, (int)blockIdx.x};
+#endif
+    const int t = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, n_tiles);
     const int tx = t % f.Gx, ty = f.ty0 + t / f.Gx;
     const int tile = ty * f.Gx + tx;
     const size_t Tn = (size_t)f.Gx * f.Gy;
@@ -531,9 +643,12 @@ int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, in
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0 || chunks_run <= 0) return GSR_OK;
     ProfileScope prof("render_bwd", s);
+    static const bool in_tile_order = [] { const char *e = getenv("GSR_BWD_TILE_ORDER"); return e && atoi(e) != 0; }();
+    if (!in_tile_order)
+        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);
     hipLaunchKernelGGL(k_render_bwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, chunks_run, iw.ranges, bw.sorted_gid,
                        bw.vals[sort_result], gw.records, cam.bg, iw.T_state, iw.last_enc, dL_dcolor,
-                       reinterpret_cast<float4 *>(bw.grad_rows));
+                       reinterpret_cast<float4 *>(bw.grad_rows), in_tile_order ? nullptr : iw.tile_order);
     GSR_LAUNCH_CHECK("render_bwd", debug, s);
     return GSR_OK;
 }

@@ -58,7 +58,8 @@ class FramePlan(C.Structure):
 class DebugViews(C.Structure):
     _fields_ = [("splat_records", C.c_void_p), ("tiles_touched", C.c_void_p), ("depth_order", C.c_void_p),
                 ("point_offsets", C.c_void_p), ("clamped", C.c_void_p), ("sorted_gaussian", C.c_void_p),
-                ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p)]
+                ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("tile_work", C.c_void_p),
+                ("tile_order", C.c_void_p)]
 
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess", "gsr_forward",
@@ -250,7 +251,9 @@ def debug_views(desc, geom_ws, binning_ws, image_ws, plan: FramePlan) -> dict:
         sorted_quadrants=(lambda t: None if t is None else (t >> 28) & 0xF)(view(binning_ws, v.sorted_gaussian, R * 4, torch.int32, (R,))),
         ranges=view(image_ws, v.ranges, MAX_CHUNKS * Tn * 8, torch.int32, (MAX_CHUNKS, Tn, 2)),
         final_T=view(image_ws, v.final_T, N * 4, torch.float32, (desc.height, desc.width)),
-        n_contrib=view(image_ws, v.n_contrib, N * 4, torch.int32, (desc.height, desc.width)))
+        n_contrib=view(image_ws, v.n_contrib, N * 4, torch.int32, (desc.height, desc.width)),
+        tile_work=view(image_ws, v.tile_work, Tn * 4, torch.int32, (Tn,)),
+        tile_order=view(image_ws, v.tile_order, Tn * 4, torch.int32, (Tn,)))
 
 
 def profile_enable(on: bool):

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(native):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gsrast.h but not exported"
     assert set(native.EXPORTS) == declared
-    assert lib.gsr_version() == 10
+    assert lib.gsr_version() == 11
 
 
 def test_argument_validation_without_gpu(native):

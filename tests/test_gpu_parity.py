@@ -1278,3 +1278,48 @@ def test_one_call_forward_falls_back_when_the_guessed_workspace_is_too_small():
     for c, r, s_ in ((c1, r1, s1), (c2, r2, s2)):
         assert torch.equal(c, c0) and torch.equal(r, r0) and torch.equal(s_, s0)
     dgr._binning_guess.clear()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,H,P,rows", [(320, 208, 6000, None), (320, 208, 6000, (3, 9)), (2560, 1616, 40_000, None)])
+def test_backward_launch_order_is_a_permutation_longest_tile_first(W, H, P, rows):
+    """K7 runs the slab's tiles longest first (k_tile_order): the order is a permutation of the slab's tiles, the work the
+    forward recorded per tile equals the deepest contributor over the tile's pixels (summed over the chunks), and it does not
+    increase along the order at the resolution of the sort's bins (9 bits of the longest tile's work).  16 160 tiles in the
+    third case: beyond the 8 192 a block keeps in registers.  The order never changes a value: the gradients equal those of a
+    launch in tile order (GSR_BWD_TILE_ORDER is read once per process, so that comparison lives in tools/ab.sh)."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _native as N
+    scene = S.make_scene(P, W, H, 1, 77, scale_lo=0.004, scale_hi=0.05)
+    kw = raster_kwargs(scene, S.make_camera(W, H))
+    rs, inp = _settings(kw), _inputs(kw, False)
+    args = (inp["means3D"], inp["shs"], None, inp["opacities"], inp["scales"], inp["rotations"], None, rs)
+    _, _, fr = dgr.rasterize_forward(*args, **({} if rows is None else {"tile_rows": rows}))
+    g = S.make_grad_image(W, H, 5).to(DEV)
+    dgr.rasterize_backward_screen(fr, g)
+    torch.cuda.synchronize()
+    v = N.debug_views(fr.desc, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan)
+    Gx, Gy = (W + 15) // 16, (H + 15) // 16
+    ty0, ty1 = (0, Gy) if rows is None else rows
+    n = (ty1 - ty0) * Gx
+    order = v["tile_order"][:n].long().cpu().numpy()
+    assert sorted(order.tolist()) == list(range(n))
+    work = v["tile_work"].long().cpu().numpy()[ty0 * Gx:ty1 * Gx]
+    enc = v["n_contrib"].long().cpu().numpy()
+    c_last, n_last = (enc >> 26) - 1, enc & ((1 << 26) - 1)
+    lens = v["ranges"].long().cpu().numpy()[:fr.plan.chunks_run]
+    lens = lens[..., 1] - lens[..., 0]
+    want = np.zeros(n, np.int64)
+    for c in range(fr.plan.chunks_run):
+        d = np.zeros((Gy * 16, Gx * 16), np.int64)
+        d[:H, :W] = np.where(c_last == c, n_last, 0)
+        want += d.reshape(Gy, 16, Gx, 16).max(axis=(1, 3)).reshape(-1)[ty0 * Gx:ty1 * Gx]
+    # (a pixel's final record names its LAST chunk only: with several chunks the earlier ones' depths are a lower bound)
+    if fr.plan.chunks_run == 1:
+        np.testing.assert_array_equal(work, want)
+    else:
+        assert np.all(work >= want)
+    assert work.max() > 0
+    shift = max(int(work.max()).bit_length() - 9, 0)
+    along = work[order] >> shift
+    assert np.all(along[1:] <= along[:-1])
