@@ -63,6 +63,23 @@ __device__ __forceinline__ void wave_sum9_to_lane63(float &a, float &b, float &c
                      GSR_DPP9("row_bcast:15") GSR_DPP9("row_bcast:31") "s_nop 1"
                  : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f_), "+v"(g), "+v"(h), "+v"(i));
 }
+
+// The same for TWO splats at once: a[] holds the first splat's nine lane sums, b[] the second's.  v_permlane32_swap trades
+// a's upper 32 lanes for b's lower 32, so a + b is "first splat, lanes l and l + 32" in the lower half of the wave and
+// "second splat" in the upper half; four row steps and row_bcast:15 finish both (row_bcast also adds lane 31's partial sum
+// into row 2: harmless, lane 63 reads row 2's lane 47 as it was before the instruction).  Totals: lane 31 (first), lane 63
+// (second).
+__device__ __forceinline__ void wave_sum9_two(float (&a)[9], float (&b)[9])
+{
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(b[i]), false, false);
+        a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    asm volatile("s_nop 1\n\t" GSR_DPP9("row_shr:1") GSR_DPP9("row_shr:2") GSR_DPP9("row_shr:4") GSR_DPP9("row_shr:8")
+                     GSR_DPP9("row_bcast:15") "s_nop 1"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]));
+}
 #undef GSR_DPP9
 
 // Sum over the 64 lanes; the total lands in lane 63 (other lanes hold partial sums).
@@ -195,6 +212,26 @@ __device__ __forceinline__ unsigned live_quadrants(const FwdPair &A, const FwdPa
     return m;
 }
 
+#if defined(GSR_BWD_TRACE) || defined(GSR_FWD_TRACE)
+// debug builds only (tools/bwd_trace.sh): per block {start, end (100 MHz clock), HW_ID, XCC_ID} of the last launch of the
+// traced kernel
+__device__ unsigned long long g_bwd_trace[4 * 65536];
+extern "C" int gsr_debug_bwd_trace(unsigned long long *host_out, int n_blocks)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bwd_trace), sizeof(unsigned long long) * 4 * (size_t)n_blocks);
+}
+struct TraceEnd {
+    unsigned long long t0; int b;
+    __device__ ~TraceEnd() {
+        if (threadIdx.x == 0 && b < 65536) {
+            g_bwd_trace[4 * b] = t0; g_bwd_trace[4 * b + 1] = wall_clock64();
+            g_bwd_trace[4 * b + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            g_bwd_trace[4 * b + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+        }
+    }
+};
+#endif
+
 __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, int n_tiles, int c, int finalize_all,
                                                       const uint2 *__restrict__ ranges_c, uint32_t *__restrict__ open,
                                                       const uint32_t *__restrict__ sorted_gid,
@@ -203,7 +240,12 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
                                                       int32_t *__restrict__ last_enc, uint32_t *__restrict__ tile_work)
 {
     __shared__ float4 sh_rec[kWave * 3];
-    const int t = xcd_remap(blockIdx.x, n_tiles);
+#ifdef GSR_FWD_TRACE
+    TraceEnd trace_end{(unsigned long long)wall_clock64(), (int)blockIdx.x};
+#endif
+    // tile = block: consecutive tiles run on different XCDs (block b -> XCD b % 8), which balances them; contiguous bands
+    // per XCD (round 1) finished up to 20 % apart at cfg3 and bought nothing measurable in L2 hits
+    const int t = (int)blockIdx.x;
     const int tx = t % f.Gx, ty = f.ty0 + t / f.Gx;
     const int tile = ty * f.Gx + tx;
     if (open[tile] == 0u) return;                       // closed by an earlier chunk: pixels are final
@@ -493,14 +535,6 @@ __global__ __launch_bounds__(kOrderThreads) void k_tile_order(int n_tiles, int t
     }
 }
 
-#ifdef GSR_BWD_TRACE
-// debug build only (tools/bwd_trace.py): per block {start, end (100 MHz clock), HW_ID, XCC_ID} of the last launch
-__device__ unsigned long long g_bwd_trace[4 * 65536];
-extern "C" int gsr_debug_bwd_trace(unsigned long long *host_out, int n_blocks)
-{
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bwd_trace), sizeof(unsigned long long) * 4 * (size_t)n_blocks);
-}
-#endif
 
 __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
                                                       const uint32_t *__restrict__ sorted_gid,
@@ -512,17 +546,7 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
 {
     __shared__ float4 sh_rec[kWave * 3];
 #ifdef GSR_BWD_TRACE
-    const unsigned long long trace_t0 = wall_clock64();
-    struct TraceEnd {
-        unsigned long long t0; int b;
-        __device__ ~TraceEnd() {
-            if (threadIdx.x == 0 && b < 65536) {
-                g_bwd_trace[4 * b] = t0; g_bwd_trace[4 * b + 1] = wall_clock64();
-                g_bwd_trace[4 * b + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-                g_bwd_trace[4 * b + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
-            }
-        }
-    } trace_end{trace_t0, (int)blockIdx.x};
+    TraceEnd trace_end{(unsigned long long)wall_clock64(), (int)blockIdx.x};
 #endif
     const int t = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, n_tiles);
     const int tx = t % f.Gx, ty = f.ty0 + t / f.Gx;
@@ -585,9 +609,9 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
                 const int mypos = base + lane;
                 mymask &= (mypos < qmax0 ? 1u : 0u) | (mypos < qmax1 ? 2u : 0u) | (mypos < qmax2 ? 4u : 0u) | (mypos < qmax3 ? 8u : 0u);
                 unsigned long long act = __ballot(mymask != 0u);       // splats with work, walked back to front
-                while (act != 0ull) {
-                    const int j = 63 - __builtin_clzll(act);
-                    act &= ~(1ull << j);
+                // One splat's pass over the tile: the lane's nine partial sums (both pairs, both pair elements added up).
+                // Returns false when no pixel of the tile accepted the splat (its row stays 0).
+                auto splat_pass = [&](int j, float (&s)[9], float &lop) -> bool {
                     const int pos = base + j;
                     const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mymask, j);
                     const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
@@ -609,21 +633,54 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
                         const bool v = bwd_pair_dispatch(m >> 2, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P1, A);
                         any_valid = any_valid || v;
                     }
-                    if (__ballot(any_valid) == 0ull) continue;                  // nobody accepted this splat: row stays 0
-                    float s0 = A.S0[0] + A.S0[1], s1 = A.S1[0] + A.S1[1], s2 = A.S2[0] + A.S2[1], s3 = A.S3[0] + A.S3[1],
-                          s4 = A.S4[0] + A.S4[1], s5 = A.S5[0] + A.S5[1], s6 = A.S6[0] + A.S6[1], s7 = A.S7[0] + A.S7[1],
-                          s8 = A.S8[0] + A.S8[1];
-                    wave_sum9_to_lane63(s0, s1, s2, s3, s4, s5, s6, s7, s8);
-                    // lane 63 holds the nine totals: it stores the splat's row itself (three 16-B stores)
-                    const uint32_t slot_j = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
-                    written |= 1ull << j;
-                    if (lane == kWave - 1) {
-                        const float inv_op = __builtin_amdgcn_exp2f(-sp.lop);              // 1 / opacity
-                        float4 *row = grad_rows + 3 * (size_t)slot_j;
-                        // -(tx cA + ty cB) = ln2 (2 qA tx + qB ty), likewise for y; gA, gB, gC carry the -1/2 of A.9
-                        row[0] = make_float4(s0 * (0.69314718f * half_w), s1 * (0.69314718f * half_h), s2 * -0.5f, s3 * -0.5f);
-                        row[1] = make_float4(s4 * -0.5f, s5 * inv_op, s6, s7);
-                        row[2] = make_float4(s8, 0.f, 0.f, 0.f);
+                    if (__ballot(any_valid) == 0ull) return false;
+                    s[0] = A.S0[0] + A.S0[1]; s[1] = A.S1[0] + A.S1[1]; s[2] = A.S2[0] + A.S2[1]; s[3] = A.S3[0] + A.S3[1];
+                    s[4] = A.S4[0] + A.S4[1]; s[5] = A.S5[0] + A.S5[1]; s[6] = A.S6[0] + A.S6[1]; s[7] = A.S7[0] + A.S7[1];
+                    s[8] = A.S8[0] + A.S8[1];
+                    lop = sp.lop;
+                    return true;
+                };
+                auto store_row = [&](const float (&s)[9], float lop, uint32_t slot_j) {
+                    const float inv_op = __builtin_amdgcn_exp2f(-lop);                  // 1 / opacity
+                    float4 *row = grad_rows + 3 * (size_t)slot_j;
+                    // -(tx cA + ty cB) = ln2 (2 qA tx + qB ty), likewise for y; gA, gB, gC carry the -1/2 of A.9
+                    row[0] = make_float4(s[0] * (0.69314718f * half_w), s[1] * (0.69314718f * half_h), s[2] * -0.5f, s[3] * -0.5f);
+                    row[1] = make_float4(s[4] * -0.5f, s[5] * inv_op, s[6], s[7]);
+                    row[2] = make_float4(s[8], 0.f, 0.f, 0.f);
+                };
+                // The accepted splats are reduced over the wave TWO at a time: v_permlane32_swap exchanges the upper half
+                // of the first splat's sums with the lower half of the second's, one add folds the halves, and the five
+                // remaining DPP steps run once for both (7 instructions per quantity for two splats instead of 12).  The
+                // first splat's totals land in lane 31, the second's in lane 63; each stores its own row.
+                while (act != 0ull) {
+                    float s1[9], lop1 = 0.f;
+                    int j1 = 0;
+                    bool have1 = false;
+                    while (act != 0ull && !have1) {
+                        j1 = 63 - __builtin_clzll(act);
+                        act &= ~(1ull << j1);
+                        have1 = splat_pass(j1, s1, lop1);
+                    }
+                    if (!have1) break;
+                    float s2[9], lop2 = 0.f;
+                    int j2 = 0;
+                    bool have2 = false;
+                    while (act != 0ull && !have2) {
+                        j2 = 63 - __builtin_clzll(act);
+                        act &= ~(1ull << j2);
+                        have2 = splat_pass(j2, s2, lop2);
+                    }
+                    if (have2) {
+                        written |= (1ull << j1) | (1ull << j2);
+                        wave_sum9_two(s1, s2);                                   // s1: splat j1 in lane 31, splat j2 in lane 63
+                        const uint32_t slot1 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j1);
+                        const uint32_t slot2 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j2);
+                        if ((lane & 31) == 31) store_row(s1, lane < 32 ? lop1 : lop2, lane < 32 ? slot1 : slot2);
+                    } else {
+                        written |= 1ull << j1;
+                        wave_sum9_to_lane63(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7], s1[8]);
+                        const uint32_t slot1 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j1);
+                        if (lane == kWave - 1) store_row(s1, lop1, slot1);
                     }
                 }
             }

@@ -1,7 +1,11 @@
-for pad in 0 6000 9500 13000 17000; do
-  export GSR_BWD_LDS_PAD=$pad
-  python bench.py --steps 30 --warmup 5 --no-secondary --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+# residency sweep of a blend kernel through dynamic LDS padding: bash tools/padtest.sh VAR "pads" [workload]
+VAR=$1; W=${3:-cfg3}
+for pad in $2; do
+  export $VAR=$pad
+  for i in 1 2; do
+  python bench.py --steps 40 --warmup 5 --no-secondary --no-cpu-baseline --workload $W 2>/dev/null | python -c "
 import sys, json
 d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('pad $pad', d['ms_per_step'], d['raster_ms_per_step'])"
+print('$VAR=$pad', d['ms_per_step'], d['raster_ms_per_step'], d['kernels'].get('render_fwd'), d['kernels'].get('render_bwd'))"
+  done
 done
