@@ -131,9 +131,11 @@ static int validate_inputs(const gsr_frame_desc *d, const gsr_camera *c, const g
     return GSR_OK;
 }
 
-// Control-block readback: the two host decisions of a frame (R / chunk plan, open-tile count) wait for 160 bytes.
-// The copy lands in pinned memory and the host POLLS an event instead of sleeping in hipStreamSynchronize: the
-// blocking wait's wake-up costs tens of microseconds of idle stream per readback at a 1.5 ms step.
+// Control-block readback: the two host decisions of a frame (R / chunk plan, open-tile count) wait for 250 bytes.  The kernel
+// in front of each decision (k_open_count) writes the block straight into host-coherent pinned memory and releases a sequence
+// number behind it (CtrlMirror); the host polls that word.  (Round 1 copied the block with hipMemcpyAsync and polled an event:
+// the copy is a 5 us kernel of its own and the event another packet, both on the critical path of a 0.8 ms step.)  A frame
+// whose geometry workspace is absent, or a stream that drains without the word arriving, falls back to the copy.
 constexpr double kReadbackTimeoutS = 30.0;
 
 static inline void cpu_pause()
@@ -145,33 +147,72 @@ static inline void cpu_pause()
 #endif
 }
 
-struct Readback {            // one per host thread, never freed (160 pinned bytes + an event; the HIP runtime may already be
-    Ctrl *pinned = nullptr;  // gone when thread-local destructors run)
+struct Readback {            // one per host thread, never freed (pinned words + an event; the HIP runtime may already be gone
+    uint32_t *words = nullptr;   // when thread-local destructors run).  words: Ctrl, then the sequence word
+    uint32_t *words_dev = nullptr;
+    uint32_t seq = 0;
     hipEvent_t ev = nullptr;
 };
 static thread_local Readback tl_readback;
+constexpr int kCtrlWords = (int)(sizeof(Ctrl) / 4);
 
-static int read_ctrl(const Ctrl *dev, Ctrl *out, hipStream_t s)
+static int readback_init(Readback &rb)
+{
+    if (rb.words) return GSR_OK;
+    void *p = nullptr;
+    GSR_HIP_CHECK(hipHostMalloc(&p, sizeof(Ctrl) + 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+    memset(p, 0, sizeof(Ctrl) + 64);
+    void *d = nullptr;
+    GSR_HIP_CHECK(hipHostGetDevicePointer(&d, p, 0));
+    GSR_HIP_CHECK(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
+    rb.words = static_cast<uint32_t *>(p);
+    rb.words_dev = static_cast<uint32_t *>(d);
+    return GSR_OK;
+}
+
+// the mirror to hand to the kernel in front of the next wait_ctrl() of this thread
+static int next_mirror(CtrlMirror *m)
 {
     Readback &rb = tl_readback;
-    if (!rb.pinned) {
-        GSR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&rb.pinned), sizeof(Ctrl), hipHostMallocDefault));
-        GSR_HIP_CHECK(hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
-    }
-    GSR_HIP_CHECK(hipMemcpyAsync(rb.pinned, dev, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
-    GSR_HIP_CHECK(hipEventRecord(rb.ev, s));
-    // Poll, politely and not for ever: a few thousand queries back to back (the readback normally lands within tens of
-    // microseconds), then with a pause instruction between queries, and after kReadbackTimeoutS give up with an error
-    // instead of hanging the host on a wedged stream.
+    int rc = readback_init(rb);
+    if (rc) return rc;
+    if (++rb.seq == 0) rb.seq = 1;
+    m->words = rb.words_dev; m->seq = rb.seq;
+    return GSR_OK;
+}
+
+static int read_ctrl_by_copy(const Ctrl *dev, Ctrl *out, hipStream_t s)
+{
+    Readback &rb = tl_readback;
+    int rc = readback_init(rb);
+    if (rc) return rc;
+    GSR_HIP_CHECK(hipMemcpyAsync(rb.words, dev, sizeof(Ctrl), hipMemcpyDeviceToHost, s));
+    GSR_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(out, rb.words, sizeof(Ctrl));
+    return GSR_OK;
+}
+
+// Wait for the block the kernel given next_mirror()'s mirror publishes.  Polls, politely and not for ever: a few thousand
+// loads back to back (the word normally lands within microseconds of the kernel's end), then with a pause instruction, now and
+// then a look at the stream (an error, or a drained stream without the word, ends the wait), and after kReadbackTimeoutS an
+// error instead of hanging the host on a wedged stream.
+static int wait_ctrl(const Ctrl *dev, Ctrl *out, hipStream_t s)
+{
+    Readback &rb = tl_readback;
+    const uint32_t want = rb.seq;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned long long spins = 0;; ++spins) {
-        const hipError_t e = hipEventQuery(rb.ev);
-        if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) { set_error("control-block readback: %s", hipGetErrorString(e)); return GSR_ERR_HIP; }
+        if (__atomic_load_n(&rb.words[kCtrlWords], __ATOMIC_ACQUIRE) == want) break;
         if (spins > 4096) {
             cpu_pause();
-            if ((spins & 1023) == 0) {
-                if (spins > (1ull << 16)) std::this_thread::yield();         // a long wait (debugger, huge frame): give the core away
+            if ((spins & 4095) == 0) {
+                const hipError_t e = hipStreamQuery(s);
+                if (e == hipSuccess) {                               // drained: the word is there now, or it is not coming
+                    if (__atomic_load_n(&rb.words[kCtrlWords], __ATOMIC_ACQUIRE) == want) break;
+                    return read_ctrl_by_copy(dev, out, s);
+                }
+                if (e != hipErrorNotReady) { set_error("control-block readback: %s", hipGetErrorString(e)); return GSR_ERR_HIP; }
+                if (spins > (1ull << 20)) std::this_thread::yield();         // a long wait (debugger, huge frame): give the core away
                 const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (waited > kReadbackTimeoutS) {
                     set_error("control-block readback did not complete within %.0f s: the stream is stuck (a kernel of this frame "
@@ -181,7 +222,7 @@ static int read_ctrl(const Ctrl *dev, Ctrl *out, hipStream_t s)
             }
         }
     }
-    *out = *rb.pinned;
+    memcpy(out, rb.words, sizeof(Ctrl));
     return GSR_OK;
 }
 
@@ -238,17 +279,19 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     plan->num_chunks = 1;
     if (f.P == 0) return GSR_OK;
     GeomWS gw = carve_geom(geom_ws, f.P);
-    GSR_HIP_CHECK(hipMemsetAsync(gw.sel, 0, sizeof(SelState), s));       // the selection's histograms
+    // (the selection's histograms are cleared by the preprocess kernel, the tile ranges by the partition's scatter kernel)
     if ((rc = launch_preprocess(f, *cam, *g, gw, radii, desc->prefiltered != 0, dbg, s))) return rc;
-    if ((rc = launch_depth_select(f, gw, dbg, s))) return rc;           // chunk plan + partition by chunk (gsr_select.hip)
     if (image_ws) {                                  // stage 2's reset of ranges / open flags, in the shadow of the readback
         ImageWS iw = carve_image(image_ws, f);
-        if ((rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
+        if ((rc = launch_depth_select(f, gw, dbg, s, iw.ranges, binning_clear_bytes(f, iw) / 16))) return rc;      // chunk plan + partition by chunk
+        CtrlMirror mirror;
+        if ((rc = next_mirror(&mirror))) return rc;
+        if ((rc = launch_binning_init(f, gw, iw, dbg, s, true, mirror))) return rc;
         plan->binning_initialised = 1;
-    }
+    } else if ((rc = launch_depth_select(f, gw, dbg, s))) return rc;
     // The one host synchronisation of this stage: the plan (R sizes the binning workspace).
     Ctrl h;
-    if ((rc = read_ctrl(gw.ctrl, &h, s))) return rc;
+    if ((rc = image_ws ? wait_ctrl(gw.ctrl, &h, s) : read_ctrl_by_copy(gw.ctrl, &h, s))) return rc;
     if (desc->prefiltered && h.prefilter_violation) {
         set_error("prefiltered is set but at least one Gaussian fails the frustum test (view depth <= 0.2): the caller's "
                   "pre-filter and the rasterizer disagree");
@@ -375,9 +418,11 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         plan->chunks_run = c + 1;
         plan->instances_emitted = -1;                 // the last chunk's count stays on the device
         if (last) break;
-        if ((rc = launch_open_update(f, gw, iw, dbg, s))) return rc;
+        CtrlMirror mirror;
+        if ((rc = next_mirror(&mirror))) return rc;
+        if ((rc = launch_open_update(f, gw, iw, dbg, s, mirror))) return rc;
         Ctrl h;
-        if ((rc = read_ctrl(gw.ctrl, &h, s))) return rc;
+        if ((rc = wait_ctrl(gw.ctrl, &h, s))) return rc;
         plan->instances_emitted = (int64_t)h.chunk_base[c + 1];
         emitted_before = (uint64_t)h.chunk_base[c + 1];
         open_now = h.open_count;

@@ -104,7 +104,7 @@ constexpr int kBinBlock = 256;
 // ---- open flags: (re)initialise for the slab, count the tiles that are still open and pack the flags into one
 // bit per tile (row-major, ceil(Gx/64) words per tile row) for the count / emit kernels (one block).
 __global__ __launch_bounds__(1024) void k_open_count(FrameK f, int init, uint32_t *__restrict__ open,
-                                                     unsigned long long *__restrict__ open_bits, Ctrl *ctrl)
+                                                     unsigned long long *__restrict__ open_bits, Ctrl *ctrl, CtrlMirror mirror)
 {
     __shared__ uint32_t sh_count, sh_stuck;
     if (threadIdx.x == 0) { sh_count = 0; sh_stuck = 0; }
@@ -127,22 +127,45 @@ __global__ __launch_bounds__(1024) void k_open_count(FrameK f, int init, uint32_
     if (lane == 0 && stuck) atomicAdd(&sh_stuck, stuck);
     __syncthreads();
     if (threadIdx.x == 0) { ctrl->open_count = sh_count; ctrl->open_stuck = sh_stuck; }
+    // This kernel is the last one in front of both host decisions of a frame (the plan; "did the frame close"): it hands the
+    // control block to the host itself, through host-coherent memory, instead of a device-to-host copy + event behind it.
+    // Every field but the two above was written by earlier kernels; the flag word goes last, released at system scope.
+    if (mirror.words) {
+        constexpr int kWords = (int)(sizeof(Ctrl) / 4);
+        static_assert(sizeof(Ctrl) % 4 == 0 && kWords <= 1024, "one thread per word");
+        if ((int)threadIdx.x < kWords) {
+            uint32_t v = reinterpret_cast<const uint32_t *>(ctrl)[threadIdx.x];
+            if (threadIdx.x == offsetof(Ctrl, open_count) / 4) v = sh_count;
+            if (threadIdx.x == offsetof(Ctrl, open_stuck) / 4) v = sh_stuck;
+            mirror.words[threadIdx.x] = v;
+            __threadfence_system();
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&mirror.words[kWords], mirror.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
-int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
+size_t binning_clear_bytes(const FrameK &f, const ImageWS &iw)
 {
+    // the per-chunk tile ranges and, directly behind them, the per-tile counters with their padding (carve_image: both are
+    // 256-byte aligned blocks, so the size is a multiple of 16)
     const size_t Tn = (size_t)f.Gx * f.Gy;
-    GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, (size_t)((char *)iw.tile_cnt - (char *)iw.ranges) + Tn * sizeof(uint32_t), s));
+    return (size_t)((char *)iw.tile_cnt - (char *)iw.ranges) + align_up((Tn ? Tn : 1) * sizeof(uint32_t));
+}
+
+int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s, bool ranges_cleared, CtrlMirror mirror)
+{
+    if (!ranges_cleared) GSR_HIP_CHECK(hipMemsetAsync(iw.ranges, 0, binning_clear_bytes(f, iw), s));
     ProfileScope prof("open_count", s);
-    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 1, iw.open, iw.open_bits, gw.ctrl);
+    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 1, iw.open, iw.open_bits, gw.ctrl, mirror);
     GSR_LAUNCH_CHECK("open_count(init)", debug, s);
     return GSR_OK;
 }
 
-int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s)
+int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s, CtrlMirror mirror)
 {
     ProfileScope prof("open_count", s);
-    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 0, iw.open, iw.open_bits, gw.ctrl);
+    hipLaunchKernelGGL(k_open_count, dim3(1), dim3(1024), 0, s, f, 0, iw.open, iw.open_bits, gw.ctrl, mirror);
     GSR_LAUNCH_CHECK("open_count", debug, s);
     return GSR_OK;
 }

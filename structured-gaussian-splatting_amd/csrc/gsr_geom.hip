@@ -78,9 +78,13 @@ __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float
                                                            const float *__restrict__ colpre, float4 *__restrict__ records,
                                                            uint2 *__restrict__ tiles_mass, uint8_t *__restrict__ clamped,
                                                            int32_t *__restrict__ radii, uint32_t *__restrict__ sort_keys,
-                                                           uint32_t *__restrict__ sort_vals, uint32_t *__restrict__ prefilter_flag)
+                                                           uint32_t *__restrict__ sort_vals, uint32_t *__restrict__ prefilter_flag,
+                                                           uint4 *__restrict__ zero16, int zero16_n)
 {
     const int i = blockIdx.x * kGeomBlock + threadIdx.x;
+    // the selection's histograms (SelState, 130 KB) start every frame at zero: cleared here, one 16-byte store per thread,
+    // instead of by a memset launch of its own in front of this kernel (the histogram kernels run after this one)
+    for (int z = i; z < zero16_n; z += (int)gridDim.x * kGeomBlock) zero16[z] = make_uint4(0u, 0u, 0u, 0u);
     if (i >= f.P) return;
     float V[16], PV[16], cp[3];
 #pragma unroll
@@ -127,7 +131,7 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
     hipLaunchKernelGGL((k_preprocess<DEG, RAW, LAZY>), dim3(grid), dim3(kGeomBlock), 0, s, f, cam.viewmatrix, cam.projmatrix,  \
                        cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs, g.shs_rest,   \
                        g.colors_precomp, ws.records, ws.tiles_mass, ws.clamped, radii, ws.sort_keys[0],                 \
-                       ws.sort_vals[0], prefilter_flag)
+                       ws.sort_vals[0], prefilter_flag, reinterpret_cast<uint4 *>(ws.sel), (int)(sizeof(SelState) / 16))
     if (g.shs) {                  // colours from SH: lazily, per binned chunk
         if (g.raw) GSR_PRE(0, true, true);
         else GSR_PRE(0, false, true);

@@ -90,7 +90,9 @@ struct SelState {               // device scratch of the selection (zeroed at th
     unsigned long long R;
     uint32_t done[2];           // tickets of the two histogram kernels: their last block runs the plan step
     uint32_t blk_cnt[GSR_MAX_CHUNKS][kSelBlocks];
+    uint32_t pad16_[2];
 };
+static_assert(sizeof(SelState) % 16 == 0, "k_preprocess clears SelState with 16-byte stores");
 
 struct Ctrl {                   // small device-side control block of one frame
     uint32_t R_total, V, num_chunks, open_count;
@@ -171,19 +173,25 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
 // ---- kernel launchers (each returns a gsr_status)
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
                       bool prefiltered, bool debug, hipStream_t s);
-int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s);
+// clear16 / clear16_n: 16-byte words the partition's scatter kernel zeroes on the side (the frame's tile ranges and counters)
+int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s, void *clear16 = nullptr, size_t clear16_n = 0);
 int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_t key_hi, bool first, GeomWS &ws, bool debug, hipStream_t s,
                        const uint32_t *live_count = nullptr);
 // parts: the range may span several planned chunks (merged by the caller); their relative keys are re-based to the first one's
 struct LiveParts { int n; uint32_t end[GSR_MAX_CHUNKS]; uint32_t delta[GSR_MAX_CHUNKS]; };      // end: position in the range; delta: added to the key
 int launch_live_filter(const FrameK &f, int c, int r0, int r1, const LiveParts &parts, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
-int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
+size_t binning_clear_bytes(const FrameK &f, const ImageWS &iw);      // ranges + tile counters: a multiple of 16
+// Where k_open_count publishes the control block for the host: sizeof(Ctrl) / 4 words of host-coherent pinned memory (device
+// address) followed by a flag word that receives `seq` last, with system-scope release.  words == nullptr: not wanted.
+struct CtrlMirror { uint32_t *words = nullptr; uint32_t seq = 0; };
+int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s, bool ranges_cleared = false,
+                        CtrlMirror mirror = CtrlMirror());
 int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, int r0, int r1, int num_visible, GeomWS &ws,
                         bool debug, hipStream_t s);
 int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max, uint64_t emitted_before, GeomWS &gw, BinningWS &bw,
                          ImageWS &iw,
                          int *sort_result, bool debug, hipStream_t s, bool filtered = false);
-int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s);
+int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s, CtrlMirror mirror = CtrlMirror());
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s);
 int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, int sort_result, const GeomWS &gw, BinningWS &bw,

@@ -113,7 +113,6 @@ __device__ __forceinline__ float bcast_lane63(float v)
 #define GSR_BWD_WAVES 4        // ... and of k_render_bwd
 #endif
 constexpr int kQuads = 4;                                   // 8x8 quadrants of a tile: k = qx + 2 qy
-constexpr int kPairs = 2;                                   // pair p = the two quadrants of rows 8p .. 8p+7: k = 2p (left), 2p + 1 (right)
 typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 operand: the lane's two pixels of a pair
 
 // Pixel mapping ("one wave, one tile", QUADRANT-major): lane l owns the pixel (l & 7, l >> 3) of each of the tile's four

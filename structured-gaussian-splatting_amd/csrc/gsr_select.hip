@@ -289,8 +289,11 @@ __host__ __device__ __forceinline__ uint32_t sel_key_base(uint32_t prev_end, boo
 __global__ __launch_bounds__(kSelThreads) void k_part_scatter(int P, const uint32_t *__restrict__ keys, const uint2 *__restrict__ tiles_mass,
                                                               const Ctrl *__restrict__ ctrl, const SelState *__restrict__ st,
                                                               uint32_t *__restrict__ order, uint32_t *__restrict__ pos_key,
-                                                              uint32_t *__restrict__ pos_tiles)
+                                                              uint32_t *__restrict__ pos_tiles, uint4 *__restrict__ clear16, int clear16_n)
 {
+    // on the side: the frame's per-chunk tile ranges and per-tile counters start at zero (no memset launch of their own)
+    for (int z = (int)(blockIdx.x * kSelThreads + threadIdx.x); z < clear16_n; z += (int)gridDim.x * kSelThreads)
+        clear16[z] = make_uint4(0u, 0u, 0u, 0u);
     __shared__ uint32_t ends[GSR_MAX_CHUNKS];
     __shared__ uint32_t sh_run[GSR_MAX_CHUNKS];                  // next free position of chunk k for this block
     __shared__ uint32_t sh_w[GSR_MAX_CHUNKS][kSelWaves], sh_pre[GSR_MAX_CHUNKS][kSelWaves];
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(kSelThreads) void k_part_scatter(int P, const uint3
     }
 }
 
-int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
+int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s, void *clear16, size_t clear16_n)
 {
     if (f.P == 0) return GSR_OK;
     const double slab_px = (double)(f.ty1 - f.ty0) * GSR_TILE * (double)f.Gx * GSR_TILE;
@@ -353,7 +356,7 @@ int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s)
         ProfileScope prof("depth_partition", s);
         hipLaunchKernelGGL(k_part_count, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], first_mass, ws.ctrl, ws.sel);
         hipLaunchKernelGGL(k_part_scatter, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, ws.ctrl, ws.sel, ws.order,
-                           ws.sort_keys[1], ws.sort_vals[1]);
+                           ws.sort_keys[1], ws.sort_vals[1], reinterpret_cast<uint4 *>(clear16), (int)clear16_n);
         GSR_LAUNCH_CHECK("depth_partition", debug, s);
     }
     return GSR_OK;

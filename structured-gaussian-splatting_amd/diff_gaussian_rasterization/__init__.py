@@ -368,6 +368,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.shapes = (means2D.shape, opacities.shape)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)         # radii's "gradient" would arrive as a zero-filled int32 [P] tensor: one launch per step
         return color, radii
 
     @staticmethod
@@ -418,6 +419,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         _stash_frame(ctx, frame)
         ctx.shapes = (means2D.shape, opacity_logits.shape)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)         # radii's "gradient" would arrive as a zero-filled int32 [P] tensor: one launch per step
         return color, radii
 
     @staticmethod

@@ -42,12 +42,25 @@ def eval_sh(deg: int, sh: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
     return res
 
 
+_ZERO_POINTS = {}
+
+
+def _zero_points(like: torch.Tensor) -> torch.Tensor:
+    """One block of zeros shaped like `like` per device (re-made when the model's size or dtype changes)."""
+    key = (like.device.type, like.device.index)
+    z = _ZERO_POINTS.get(key)
+    if z is None or z.shape != like.shape or z.dtype != like.dtype:
+        z = _ZERO_POINTS[key] = torch.zeros_like(like, requires_grad=False)
+    return z
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     """Render the scene.  Background tensor (bg_color) must be on the GPU."""
     xyz = pc.get_xyz
     # (the reference builds this as zeros_like(...) + 0 and retain_grad()s the non-leaf result; a leaf with requires_grad keeps
-    # its .grad by itself and costs one fill instead of a fill and an add over P x 3)
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
+    # its .grad by itself.  Its VALUES are never read, by the rasterizer or by the training loop, only its .grad: every frame
+    # gets a fresh leaf over one shared block of zeros per device instead of a 12 P-byte fill of its own)
+    screenspace_points = _zero_points(xyz).detach().requires_grad_(True)
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),

@@ -21,3 +21,10 @@ print("steps", cnt, "span us %.1f busy us %.1f idle us %.1f" % (tot["span"] / cn
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
     if k.startswith("gap"):
         print("%8.1f us/step  %s" % (v / cnt / 1e3, k))
+if len(sys.argv) > 2 and sys.argv[2] == "--seq":             # one warm step, launch by launch: start, duration, gap before
+    a, b = steps[len(steps) // 2]
+    t0 = ev[a][0]
+    prev_end = ev[a][0]
+    for s0, e0, n0 in ev[a:b]:
+        print("%8.1f  dur %7.1f  gap %6.1f  %s" % ((s0 - t0) / 1e3, (e0 - s0) / 1e3, (s0 - prev_end) / 1e3, n0.split("(")[0][-70:]))
+        prev_end = e0
