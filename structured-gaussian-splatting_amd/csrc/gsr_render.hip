@@ -460,7 +460,8 @@ __device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &s
 // value.
 constexpr int kOrderBins = 4096;
 constexpr int kOrderThreads = 1024;
-constexpr int kOrderPer = 8;                 // tiles a thread keeps in registers (frames up to 8192 tiles: 1080p has 8160)
+// kOrderPer: tiles a thread keeps in registers (8: frames up to 8192 tiles, 1080p has 8160; 32: up to 32768, 4K has 32400)
+template <int kOrderPer>
 __global__ __launch_bounds__(kOrderThreads) void k_tile_order(int n_tiles, int tile_base, const uint32_t *__restrict__ tile_work,
                                                               uint32_t *__restrict__ tile_order)
 {
@@ -701,7 +702,12 @@ int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, in
     ProfileScope prof("render_bwd", s);
     static const bool in_tile_order = [] { const char *e = getenv("GSR_BWD_TILE_ORDER"); return e && atoi(e) != 0; }();
     if (!in_tile_order)
-        hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);
+    {
+        if (n_tiles <= 8 * kOrderThreads)
+            hipLaunchKernelGGL(k_tile_order<8>, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);
+        else
+            hipLaunchKernelGGL(k_tile_order<32>, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);
+    }
     hipLaunchKernelGGL(k_render_bwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, chunks_run, iw.ranges, bw.sorted_gid,
                        bw.vals[sort_result], gw.records, cam.bg, iw.T_state, iw.last_enc, dL_dcolor,
                        reinterpret_cast<float4 *>(bw.grad_rows), in_tile_order ? nullptr : iw.tile_order);

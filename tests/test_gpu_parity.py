@@ -1281,12 +1281,13 @@ def test_one_call_forward_falls_back_when_the_guessed_workspace_is_too_small():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("W,H,P,rows", [(320, 208, 6000, None), (320, 208, 6000, (3, 9)), (2560, 1616, 40_000, None)])
+@pytest.mark.parametrize("W,H,P,rows", [(320, 208, 6000, None), (320, 208, 6000, (3, 9)), (2560, 1616, 40_000, None),
+                                          (4096, 2176, 40_000, None)])
 def test_backward_launch_order_is_a_permutation_longest_tile_first(W, H, P, rows):
     """K7 runs the slab's tiles longest first (k_tile_order): the order is a permutation of the slab's tiles, the work the
     forward recorded per tile equals the deepest contributor over the tile's pixels (summed over the chunks), and it does not
     increase along the order at the resolution of the sort's bins (9 bits of the longest tile's work).  16 160 tiles in the
-    third case: beyond the 8 192 a block keeps in registers.  The order never changes a value: the gradients equal those of a
+    third case (the 32-per-thread instantiation), 34 816 in the fourth: beyond what a block keeps in registers.  The order never changes a value: the gradients equal those of a
     launch in tile order (GSR_BWD_TILE_ORDER is read once per process, so that comparison lives in tools/ab.sh)."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _native as N
