@@ -69,8 +69,9 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
         # a14: exp / normalize / sigmoid of (3 + 4 + 1) floats per Gaussian: 32 in + 32 out; backward reads the 8 incoming
         # gradients, the saved outputs / raw quaternion (8) and writes 8
         "activations_fwd": 64 * P, "activations_bwd": 96 * P,
-        "render_fwd": 40 * Re + 20 * N,                     # K6: id 4 + record 36 per instance; 20 B/px
-        "render_bwd": 76 * Re + 20 * N,                     # K7: 40 read + 36 written per instance; 20 B/px
+        "render_fwd": 40 * Re + 20 * N + 4 * Tn,            # K6: id 4 + record 36 per instance; 20 B/px; per tile its walked depth out
+        "render_bwd": 76 * Re + 20 * N + 4 * Tn,            # K7: 40 read + 36 written per instance; 20 B/px; its tile from the launch order
+        "tile_order": 8 * Tn,                               # K7's launch order (longest tile first): work in, order out
         "reduce_rows": 36 * Re + 36 * Vb,                   # deterministic reduction (replaces atomic RMW)
         "geom_bwd": 4 * geom_rows + (99 + 12 * K) * Vlive + (40 + 12 * M) * geom_written,        # K8 + K9
         "loss_fwd": 20 * C * N, "loss_bwd": 24 * C * N,

@@ -27,7 +27,7 @@ NAMES = {
     "void gsr::k_bin_chunk<true>": "emit", "gsr::k_ranges": "ranges", "gsr::k_tile_gather": "tile_gather",
     "gsr::k_tile_ranges": "tile_ranges", "void gsr::k_sel_hist<": "depth_hist", "gsr::k_part_count": "depth_partition",
     "gsr::k_part_scatter": "depth_partition", "gsr::k_chunk_sort_small": "chunk_sort", "gsr::k_zero_segments": "zero_outputs",
-    "gsr::k_act_fwd": "activations_fwd", "gsr::k_act_bwd": "activations_bwd",
+    "gsr::k_act_fwd": "activations_fwd", "gsr::k_act_bwd": "activations_bwd", "void gsr::k_tile_order<": "tile_order",
 }
 SKIP_FIRST = 3
 

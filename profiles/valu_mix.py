@@ -96,14 +96,17 @@ def mix(pmc_csv, isa_path, out_path):
         movs = sum(c for m, c in n.items() if m.startswith("v_mov") or m.startswith("v_accvgpr"))
         others_static = sum(c for m, c in n.items() if re.match(r"v_(cmp|cndmask|min|max|med3|mov|readlane|readfirstlane|and|or|lshl|bfe|add_f32_dpp)", m)) or 1
         s_mov = min(movs / others_static, 1.0)
+        perm = sum(c for m, c in n.items() if m.startswith("v_permlane32_swap"))       # two-splat wave reduction (round 2): 8.2 cycles
+        s_perm = min(perm / (others_static + perm), 1.0)
         counts = {
             "v_pk_fma_f32": fma * s_fma, "v_fma_f32": fma * (1 - s_fma), "v_pk_mul_f32": mul * s_mul, "v_mul_f32": mul * (1 - s_mul),
-            "v_pk_add_f32": add * s_add, "v_add_f32_dpp": add * s_dpp, "v_add_f32": add * (1 - s_add - s_dpp), "v_exp_f32": trans, "v_mov_b32": other * s_mov + i32 + cvt,
-            "v_cndmask_b32(sgpr)": other * (1 - s_mov),       # compares, selects, min/max, DPP adds: 4.2-cycle class
+            "v_pk_add_f32": add * s_add, "v_add_f32_dpp": add * s_dpp, "v_add_f32": add * (1 - s_add - s_dpp), "v_exp_f32": trans, "v_mov_b32": other * (1 - s_perm) * s_mov + i32 + cvt,
+            "v_permlane32_swap_b32": other * s_perm,
+            "v_cndmask_b32(sgpr)": other * (1 - s_perm) * (1 - s_mov),       # compares, selects, min/max: 4.2-cycle class
         }
         out["kernels"][key] = {"insts_valu": tot, "launches_sampled": len(ctr.get("SQ_INSTS_VALU", [])) - SKIP_FIRST,
                                "pmc_per_launch": {k: round(v) for k, v in avg.items()},
-                               "static_packed_share": {"fma": round(s_fma, 3), "mul": round(s_mul, 3), "add": round(s_add, 3), "dpp_of_add": round(s_dpp, 3), "mov_of_other": round(s_mov, 3)},
+                               "static_packed_share": {"fma": round(s_fma, 3), "mul": round(s_mul, 3), "add": round(s_add, 3), "dpp_of_add": round(s_dpp, 3), "mov_of_other": round(s_mov, 3), "permlane_of_other": round(s_perm, 3)},
                                "class_share": {k: round(v / tot, 4) if tot else 0.0 for k, v in counts.items()}}
     json.dump(out, open(out_path, "w"), indent=1)
     print(json.dumps(out["kernels"], indent=1))

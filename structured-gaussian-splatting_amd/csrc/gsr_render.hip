@@ -699,15 +699,16 @@ int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, in
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0 || chunks_run <= 0) return GSR_OK;
-    ProfileScope prof("render_bwd", s);
     static const bool in_tile_order = [] { const char *e = getenv("GSR_BWD_TILE_ORDER"); return e && atoi(e) != 0; }();
-    if (!in_tile_order)
-    {
+    if (!in_tile_order) {
+        ProfileScope prof("tile_order", s);
         if (n_tiles <= 8 * kOrderThreads)
             hipLaunchKernelGGL(k_tile_order<8>, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);
         else
             hipLaunchKernelGGL(k_tile_order<32>, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);
+        GSR_LAUNCH_CHECK("tile_order", debug, s);
     }
+    ProfileScope prof("render_bwd", s);
     hipLaunchKernelGGL(k_render_bwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, chunks_run, iw.ranges, bw.sorted_gid,
                        bw.vals[sort_result], gw.records, cam.bg, iw.T_state, iw.last_enc, dL_dcolor,
                        reinterpret_cast<float4 *>(bw.grad_rows), in_tile_order ? nullptr : iw.tile_order);
