@@ -71,14 +71,21 @@ __device__ __forceinline__ void wave_sum9_to_lane63(float &a, float &b, float &c
 // (second).
 __device__ __forceinline__ void wave_sum9_two(float (&a)[9], float (&b)[9])
 {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[i]), __float_as_uint(b[i]), false, false);
-        a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    asm volatile("s_nop 1\n\t" GSR_DPP9("row_shr:1") GSR_DPP9("row_shr:2") GSR_DPP9("row_shr:4") GSR_DPP9("row_shr:8")
+    // one asm block: the swaps work in place on both operands (b is dead afterwards), so no copies and no per-swap wait
+    // states; the leading s_nop covers the instructions that produced the inputs
+#define GSR_SWAP(i, j) "v_permlane32_swap_b32 %" #i ", %" #j "\n\t"
+#define GSR_ADD(i, j) "v_add_f32 %" #i ", %" #i ", %" #j "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 GSR_SWAP(0, 9) GSR_SWAP(1, 10) GSR_SWAP(2, 11) GSR_SWAP(3, 12) GSR_SWAP(4, 13) GSR_SWAP(5, 14) GSR_SWAP(6, 15)
+                 GSR_SWAP(7, 16) GSR_SWAP(8, 17)
+                 GSR_ADD(0, 9) GSR_ADD(1, 10) GSR_ADD(2, 11) GSR_ADD(3, 12) GSR_ADD(4, 13) GSR_ADD(5, 14) GSR_ADD(6, 15)
+                 GSR_ADD(7, 16) GSR_ADD(8, 17)
+                 "s_nop 1\n\t" GSR_DPP9("row_shr:1") GSR_DPP9("row_shr:2") GSR_DPP9("row_shr:4") GSR_DPP9("row_shr:8")
                      GSR_DPP9("row_bcast:15") "s_nop 1"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]));
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
+                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]));
+#undef GSR_SWAP
+#undef GSR_ADD
 }
 #undef GSR_DPP9
 
@@ -379,7 +386,13 @@ struct BwdPair {             // state of a lane's two pixels in one pair of quad
     v2f ar, ag, ab;                    // colour behind the current splat
     int limit0, limit1;                // contributors of the current chunk each pixel takes part in
 };
-struct BwdAcc { v2f S0, S1, S2, S3, S4, S5, S6, S7, S8; };     // the lane's nine partial sums of one splat, per pair element
+struct BwdAcc { v2f S0, S1, S2, S3, S4, S5, S6, S7, S8; };
+__device__ __forceinline__ float add_halves(v2f v)
+{
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
+    return r;
+}     // the lane's nine partial sums of one splat, per pair element
 
 template <int MODE>          // 3: both quadrants of the pair (packed), 1: the left one only, 2: the right one only
 __device__ __forceinline__ bool bwd_pair(const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
@@ -634,9 +647,10 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
                         any_valid = any_valid || v;
                     }
                     if (__ballot(any_valid) == 0ull) return false;
-                    s[0] = A.S0[0] + A.S0[1]; s[1] = A.S1[0] + A.S1[1]; s[2] = A.S2[0] + A.S2[1]; s[3] = A.S3[0] + A.S3[1];
-                    s[4] = A.S4[0] + A.S4[1]; s[5] = A.S5[0] + A.S5[1]; s[6] = A.S6[0] + A.S6[1]; s[7] = A.S7[0] + A.S7[1];
-                    s[8] = A.S8[0] + A.S8[1];
+                    // (nine plain adds: left to itself the compiler transposes the pairs with twelve moves to use packed adds)
+                    s[0] = add_halves(A.S0); s[1] = add_halves(A.S1); s[2] = add_halves(A.S2); s[3] = add_halves(A.S3);
+                    s[4] = add_halves(A.S4); s[5] = add_halves(A.S5); s[6] = add_halves(A.S6); s[7] = add_halves(A.S7);
+                    s[8] = add_halves(A.S8);
                     lop = sp.lop;
                     return true;
                 };
