@@ -1,0 +1,92 @@
+"""Host-side timeline of one training step (cfg3, GaussianModel): wall-clock stamps at the library's entry points, averaged
+over steady-state steps, no profiler attached.  Shows how long the host needs between the forward's last readback and the
+launch of the blend backward (the stretch in which the stream can run dry)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "structured-gaussian-splatting_amd")]
+import torch
+import scene_synth as S
+from gaussian_params import Pipe
+import gaussian_renderer
+from scene import GaussianModel
+import loss_utils
+import diff_gaussian_rasterization as dgr
+from diff_gaussian_rasterization import _native as N
+
+dev = "cuda:0"
+wl = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+cfg = S.CONFIGS[wl]
+scene, cam = S.make_config(wl); scene, cam = scene.to(dev), cam.to(dev)
+gm = GaussianModel(scene.sh_degree); gm.adopt_scene(scene, device=dev)
+bg = torch.zeros(3, device=dev); gt = torch.rand(3, cfg["H"], cfg["W"], device=dev); pipe = Pipe()
+ps = list(gm._t.values())
+T = []
+now = time.perf_counter_ns
+
+
+def wrap(mod, name, tag):
+    f = getattr(mod, name)
+    def g(*a, **k):
+        T.append((tag + ">", now()))
+        r = f(*a, **k)
+        T.append((tag + "<", now()))
+        return r
+    setattr(mod, name, g)
+
+
+wrap(N, "forward_both", "native forward (both stages, 2 readbacks)")
+wrap(N, "loss_forward", "native loss fwd")
+wrap(N, "loss_backward", "native loss bwd")
+wrap(N, "backward_render", "native backward_render")
+wrap(N, "backward_geom", "native backward_geom")
+wrap(N, "activations_forward", "native act fwd")
+wrap(N, "activations_backward", "native act bwd")
+if os.environ.get("FINE"):
+    wrap(dgr, "_alloc_grads", "  _alloc_grads")
+    wrap(dgr, "_workspace", "  _workspace")
+    wrap(dgr, "rasterize_forward", " rasterize_forward")
+    wrap(dgr, "prepare_backward", " prepare_backward")
+    wrap(dgr, "rasterize_backward_screen", " rasterize_backward_screen")
+    wrap(dgr, "rasterize_backward_geom", " rasterize_backward_geom")
+    wrap(N, "Grads", "   N.Grads()")
+
+
+def step():
+    T.append(("step>", now()))
+    for p in ps: p.grad = None
+    out = gaussian_renderer.render(cam, gm, pipe, bg)
+    T.append(("render() returned", now()))
+    loss = loss_utils.training_loss(out["render"], gt)
+    T.append(("training_loss returned", now()))
+    loss.backward()
+    T.append(("backward() returned", now()))
+
+
+for _ in range(30): step()
+torch.cuda.synchronize()
+T.clear()
+def _stat():
+    s = torch.cuda.memory_stats(dev)
+    return {k: s.get(k, 0) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams", "allocation.all.allocated")}
+_s0 = _stat()
+t0 = time.perf_counter()
+for _ in range(200): step()
+torch.cuda.synchronize()
+print("ms/step %.4f (with stamps)" % (1e3 * (time.perf_counter() - t0) / 200))
+_s1 = _stat(); print("allocator per step:", {k: (_s1[k] - _s0[k]) / 200 for k in _s0})
+# average offset of each tag from its step's start
+import collections
+acc, cnt = collections.OrderedDict(), collections.Counter()
+start = None
+for tag, t in T:
+    if tag == "step>":
+        start = t; seen = collections.Counter()
+    seen[tag] += 1
+    key = tag if seen[tag] == 1 else "%s #%d" % (tag, seen[tag])
+    acc[key] = acc.get(key, 0) + (t - start); cnt[key] += 1
+prev = 0.0
+for k, v in acc.items():
+    off = v / cnt[k] / 1e3
+    print("%9.1f us  (+%6.1f)  %s" % (off, off - prev, k))
+    prev = off
+
