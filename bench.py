@@ -37,6 +37,18 @@ for _p in (ROOT, PKG):
 
 import torch  # noqa: E402
 
+_GC_LOG, _GC_T0 = [], [0.0]
+
+
+def _gc_cb(phase, info):                     # what the interpreter's cyclic collector takes out of a timed window
+    if phase == "start":
+        _GC_T0[0] = time.perf_counter()
+    else:
+        _GC_LOG.append(time.perf_counter() - _GC_T0[0])
+
+
+gc.callbacks.append(_gc_cb)
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -110,6 +122,10 @@ def main():
     shared_device = world > n_dev          # rehearsal on a box with fewer GPUs than ranks: ranks share devices
     torch.cuda.set_device(local_rank % n_dev)
     dev = torch.device("cuda", local_rank % n_dev)
+    bound = None
+    if os.environ.get("GSR_BENCH_BIND", "1") != "0":
+        from diff_gaussian_rasterization.hostbind import bind_to_gpu_numa_node
+        bound = bind_to_gpu_numa_node(local_rank % n_dev, all_threads=os.environ.get("GSR_BENCH_BIND") == "all")
     dist = None
     collectives = None
     if world > 1 or args.force_sharded:
@@ -147,6 +163,8 @@ def main():
         "config": {**m["config"], "parallelism": "single" if not ctx["sharded_on"] else f"tile-row slabs x{world}",
                    **({"collectives": collectives} if collectives else {})},
         "raster_ms_per_step": m["raster_ms_per_step"], "profiled_ms_per_step": m["profiled_ms_per_step"],
+        "gc_in_timed_window": m["gc_in_timed_window"],
+        "host": {"bound_to_numa_node": bound[0] if bound else None, "cpus": len(os.sched_getaffinity(0))},
         "kernels": m["kernels"], "roofline": m["roofline"], "cpu_baseline": None,
     }
     for k in ("torch_getters", "fused_activations", "getter_fusion", "reference_loss_composition"):
@@ -222,11 +240,14 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    gc_log, last_gc = _GC_LOG, {}
+
     def timed(n, w):
         gc.collect()                 # a generation-2 collection landing inside a 30 ms window is a 40 ms outlier (measured);
         for _ in range(w):           # collect before the warm-up, so that the device is busy again when the clock starts
             step()
         sync()
+        gc_log.clear()
         t0 = time.perf_counter()
         per_step = []
         for _ in range(n):
@@ -234,12 +255,15 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
             if os.environ.get("GSR_BENCH_TRACE"):
                 torch.cuda.synchronize(dev); per_step.append(round(1e3 * (time.perf_counter() - t0), 2))
         sync()
+        elapsed = time.perf_counter() - t0
+        last_gc["collections"], last_gc["ms"] = len(gc_log), round(1e3 * sum(gc_log), 3)
         if per_step:
             print("trace", per_step, file=sys.stderr)
-        return time.perf_counter() - t0, o
+        return elapsed, o
 
     # (1) the timed region: EXACTLY K steps, no instrumentation inside
     elapsed, out = timed(steps, warmup)
+    gc_headline = dict(last_gc)
     # (2) the same K steps again with the library's per-kernel hipEvent pairs (roofline); the event packets
     # add ~10 us between kernels, so this pass is reported separately and never feeds `value`
     prof, elapsed_profiled = {}, 0.0
@@ -354,6 +378,7 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
                    "chunks_planned": stats["chunks_planned"], "binned_gaussians": Vb, "gaussians_with_gradient": Vlive,
                    "emitted_over_num_rendered": round(Re / max(R, 1), 4)},
         "raster_ms_per_step": round(raster_ms, 4), "profiled_ms_per_step": round(1e3 * elapsed_profiled / steps, 4),
+        "gc_in_timed_window": gc_headline,
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in per_kernel.items()},
         "roofline": roofline,
     })

@@ -51,6 +51,32 @@ if os.environ.get("FINE"):
     wrap(N, "Grads", "   N.Grads()")
 
 
+if os.environ.get("AG"):
+    def _alloc_grads_instr(fr, needs, alloc):
+        P, M, dev_ = fr.desc.P, fr.M, fr.device
+        T.append(("   ag: enter", now()))
+        (_, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest) = fr.keep
+        T.append(("   ag: unpacked keep", now()))
+        def mk(flag, present, *shape):
+            return alloc(*shape, dtype=torch.float32, device=dev_) if (flag and present) else None
+        t0_ = mk(needs[0], True, P, 3); T.append(("   ag: t0", now()))
+        t1_ = mk(needs[1], True, P, 3); T.append(("   ag: t1", now()))
+        t2_ = mk(needs[2], sh is not None, P, 1 if fr.raw else M, 3); T.append(("   ag: t2 (sh)", now()))
+        t3_ = mk(needs[3], colors_precomp is not None, P, 3)
+        t4_ = mk(needs[4], True, P, 1); T.append(("   ag: t4", now()))
+        t5_ = mk(needs[5], scales is not None, P, 3)
+        t6_ = mk(needs[6], rotations is not None, P, 4); T.append(("   ag: t6", now()))
+        t7_ = mk(needs[7], cov3D_precomp is not None, P, 6)
+        t8_ = mk(fr.raw and len(needs) > 8 and needs[8], sh_rest is not None, P, M - 1, 3); T.append(("   ag: t8", now()))
+        t = (t0_, t1_, t2_, t3_, t4_, t5_, t6_, t7_, t8_)
+        ptrs = []
+        for i, x in enumerate(t):
+            ptrs.append(N._ptr(x)); T.append(("   ag: ptr%d" % i, now()))
+        grads = N.Grads(*ptrs, 0); T.append(("   ag: Grads", now()))
+        return t, grads
+    dgr._alloc_grads = _alloc_grads_instr
+
+
 def step():
     T.append(("step>", now()))
     for p in ps: p.grad = None
