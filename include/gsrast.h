@@ -84,6 +84,10 @@ typedef struct gsr_frame_plan {
                                                      gsr_forward_render (after GSR_ERR_WORKSPACE) does not sort them again   */
     int32_t chunks_filtered;                      /* bit c: chunk c was put through the live filter (only the Gaussians that can still
                                                      reach an open tile sit at the front of its range, sorted and binned)        */
+    int32_t tile_order_ready;                     /* set by gsr_forward when its zero fill also sorted the slab's tiles for the blend
+                                                     backward's launch order (gsr_backward_render then skips that launch); cleared
+                                                     by gsr_forward_render                                                      */
+    int32_t reserved_;
 } gsr_frame_plan;
 
 typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */

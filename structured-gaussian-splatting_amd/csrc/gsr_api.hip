@@ -329,7 +329,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
     const bool dbg = desc->debug != 0;
     const FrameK f = make_frame(*desc);
     ImageWS iw = carve_image(image_ws, f);
-    plan->chunks_run = 0; plan->instances_emitted = 0; plan->sort_result = 0;
+    plan->chunks_run = 0; plan->instances_emitted = 0; plan->sort_result = 0; plan->tile_order_ready = 0;
     if (f.P == 0 || plan->num_rendered == 0) {
         // nothing to bin: one blend pass over empty ranges writes the background
         GeomWS gw0 = carve_geom(geom_ws, f.P);
@@ -451,9 +451,12 @@ int gsr_forward(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gau
     if (early_fill && !early_fill->prezeroed && desc->P > 0 && plan->num_rendered > 0 && plan->chunks_run > 0 &&
         (long long)plan->chunk_rank_begin[plan->chunks_run] * 4 < (long long)desc->P) {
         const FrameK f = make_frame(*desc);
+        const ImageWS iw = carve_image(image_ws, f);
+        bool ordered = false;
         ProfileScope prof("zero_outputs", (hipStream_t)stream);
-        if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream))) return rc;
+        if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream, &iw, &ordered))) return rc;
         early_fill->prezeroed = 1;
+        plan->tile_order_ready = ordered ? 1 : 0;        // the fill carried the blend backward's launch order
     }
     return GSR_OK;
 }
@@ -510,7 +513,7 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     BinningWS bw = carve_binning(binning_ws, plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered);
     bw.grad_rows = (float *)rows_ws;
     if (plan->num_rendered > 0 &&
-        (rc = launch_render_bwd(f, *cam, plan->chunks_run, plan->sort_result, gw, bw, iw, dL_dcolor, dbg, s)))
+        (rc = launch_render_bwd(f, *cam, plan->chunks_run, plan->sort_result, gw, bw, iw, dL_dcolor, dbg, s, plan->tile_order_ready != 0)))
         return rc;
     // only the depth ranks of chunks that ran can own gradient rows
     const int n_ranks = (plan->num_rendered > 0 && plan->chunks_run > 0) ? plan->chunk_rank_begin[plan->chunks_run] : 0;

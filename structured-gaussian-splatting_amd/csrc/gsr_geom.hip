@@ -6,6 +6,7 @@
 // 48 (screen grads) + 44 + 12K + 5 and writes 40 + 12M.  Camera matrices are wave-uniform loads that
 // the compiler scalarises (s_load) — they never cost vector memory bandwidth.
 #include "gsr_internal.h"
+#include "gsr_tile_order.h"
 
 namespace gsr {
 
@@ -535,11 +536,26 @@ struct ZeroSegs {
     int n;
 };
 
-__global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z)
+// ORDER: block 0 sorts the slab's tiles for the blend backward's launch order instead of filling (gsr_tile_order.h): the
+// frame's forward is complete when this kernel runs, nothing reads the order before the backward, and the sort (one block,
+// ~10 us) disappears behind the other blocks' 45 us of stores: no launch, no stream time of its own.
+struct TileOrderArgs { int n_tiles, tile_base; const uint32_t *work; uint32_t *order; };
+constexpr int kFillOrderPer = 8192 / kGeomBlock;       // tiles per thread of block 0: frames of up to 8192 tiles
+
+template <bool ORDER>
+__global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z, TileOrderArgs o)
 {
+    unsigned block = blockIdx.x, blocks = gridDim.x;
+    if constexpr (ORDER) {
+        if (blockIdx.x == 0) {
+            tile_order_block<kGeomBlock, kFillOrderPer>(o.n_tiles, o.tile_base, o.work, o.order);
+            return;
+        }
+        block -= 1; blocks -= 1;
+    }
     const size_t total = z.end[z.n - 1];
-    const size_t stride = (size_t)gridDim.x * kGeomBlock * 4;
-    for (size_t v = ((size_t)blockIdx.x * kGeomBlock + threadIdx.x) * 4; v < total; v += stride) {
+    const size_t stride = (size_t)blocks * kGeomBlock * 4;
+    for (size_t v = ((size_t)block * kGeomBlock + threadIdx.x) * 4; v < total; v += stride) {
         int sgm = 0;
         while (v >= z.end[sgm]) ++sgm;
         const size_t off = v - (sgm ? z.end[sgm - 1] : 0);           // multiple of 4 inside the segment
@@ -552,8 +568,10 @@ __global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z)
 }
 
 // zero-fill of the backward's outputs in ONE launch: screen-space gradients (optional) + every wanted parameter gradient
-int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s)
+int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
+                        const ImageWS *order_iw, bool *ordered)
 {
+    if (ordered) *ordered = false;
     const size_t P = (size_t)f.P;
     ZeroSegs z;
     z.n = 0;
@@ -573,7 +591,15 @@ int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, 
     const size_t total = z.end[z.n - 1];
     size_t blocks = (total / 4 + kGeomBlock - 1) / kGeomBlock / 4 + 1;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_zero_segments, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z);
+    const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
+    static_assert(kGeomBlock == 256 && kOrderBins % kGeomBlock == 0, "tile_order_block<kGeomBlock, ...> inside the fill");
+    if (order_iw && n_tiles > 0 && n_tiles <= kFillOrderPer * kGeomBlock) {
+        const TileOrderArgs o{n_tiles, f.ty0 * f.Gx, order_iw->tile_work, order_iw->tile_order};
+        hipLaunchKernelGGL(k_zero_segments<true>, dim3((unsigned)blocks + 1), dim3(kGeomBlock), 0, s, z, o);
+        if (ordered) *ordered = true;
+    } else {
+        hipLaunchKernelGGL(k_zero_segments<false>, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z, TileOrderArgs{0, 0, nullptr, nullptr});
+    }
     GSR_LAUNCH_CHECK("zero_outputs", false, s);
     return GSR_OK;
 }

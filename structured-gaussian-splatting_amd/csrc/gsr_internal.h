@@ -195,8 +195,11 @@ int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hip
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s);
 int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, int sort_result, const GeomWS &gw, BinningWS &bw,
-                      const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s);
-int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s);
+                      const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s, bool order_ready = false);
+// order_iw: also sort the slab's tiles for the blend backward's launch order inside the fill (frames of up to 8192 tiles;
+// *ordered says whether it did)
+int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
+                        const ImageWS *order_iw = nullptr, bool *ordered = nullptr);
 int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
                        float *screen_grads, int prezeroed, bool debug, hipStream_t s);
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,

@@ -15,6 +15,7 @@
 //   * workgroup = one wave (64 threads): blockIdx -> tile goes through an XCD-aware bijective remap so
 //     the 8 XCDs each walk a contiguous run of tiles and neighbouring tiles share an L2.
 #include "gsr_internal.h"
+#include "gsr_tile_order.h"
 
 namespace gsr {
 
@@ -464,90 +465,14 @@ __device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &s
     return bwd_pair<3>(sp, lp, dx, dy, pos, P, A);
 }
 
-// Launch order of K7: the tiles of the slab by the work the forward measured, longest first.  All of a frame's tiles are
-// resident or queued at once (one wave each, 4 per SIMD) and a wave lives for a third of the kernel, so the launch ends with
-// the SIMDs draining: in tile order that tail was 45 % of the kernel at cfg3 (tools/bwd_trace.py) and the XCDs, which own
-// contiguous bands of tiles, finished up to 60 us apart.  Longest first, dealt round-robin over the XCDs (block b runs on XCD
-// b % 8), evens the XCDs out and leaves the shortest tiles for the end.  One block: counting sort on min(work, 4095),
-// descending.  Tiles of equal work land in the order their atomics did: the order decides which block runs a tile, never a
-// value.
-constexpr int kOrderBins = 4096;
-constexpr int kOrderThreads = 1024;
-// kOrderPer: tiles a thread keeps in registers (8: frames up to 8192 tiles, 1080p has 8160; 32: up to 32768, 4K has 32400)
+// Launch order of K7 (gsr_tile_order.h): the slab's tiles by the work the forward measured, longest first.  Its own launch
+// only when the forward's zero fill did not carry it (k_zero_segments<true>, gsr_geom.hip) or the frame has more than 8192 tiles.
 template <int kOrderPer>
 __global__ __launch_bounds__(kOrderThreads) void k_tile_order(int n_tiles, int tile_base, const uint32_t *__restrict__ tile_work,
                                                               uint32_t *__restrict__ tile_order)
 {
-    __shared__ uint32_t hist[kOrderBins];
-    __shared__ uint32_t sh_wave[kOrderThreads / kWave];
-    __shared__ uint32_t sh_max;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int j = threadIdx.x; j < kOrderBins; j += kOrderThreads) hist[j] = 0;
-    if (threadIdx.x == 0) sh_max = 0;
-    uint32_t w[kOrderPer], mx = 0;
-#pragma unroll
-    for (int i = 0; i < kOrderPer; ++i) {
-        const int t = threadIdx.x + i * kOrderThreads;
-        w[i] = t < n_tiles ? tile_work[tile_base + t] : 0u;
-        mx = w[i] > mx ? w[i] : mx;
-    }
-    for (int t = threadIdx.x + kOrderPer * kOrderThreads; t < n_tiles; t += kOrderThreads) { const uint32_t v = tile_work[tile_base + t]; mx = v > mx ? v : mx; }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { const uint32_t u = (uint32_t)__shfl_xor((int)mx, off); mx = u > mx ? u : mx; }
-    __syncthreads();
-    if (lane == 0) atomicMax(&sh_max, mx);
-    __syncthreads();
-    // bin = work scaled to 9 bits (the longest tile -> 511), three low bits from the tile index: equal work spreads over
-    // eight counters instead of queueing on one LDS address
-    int shift = 0;
-    while ((sh_max >> shift) > 511u) ++shift;
-    auto bin_of = [&](uint32_t work, int t) { return (kOrderBins - 1) - (int)(((work >> shift) << 3) | (uint32_t)(7 - (t & 7))); };
-    uint32_t slot[kOrderPer];
-#pragma unroll
-    for (int i = 0; i < kOrderPer; ++i) {
-        const int t = threadIdx.x + i * kOrderThreads;
-        if (t < n_tiles) slot[i] = atomicAdd(&hist[bin_of(w[i], t)], 1u);
-    }
-    __syncthreads();                                   // the register-held tiles own the first slots of their bins
-    for (int t = threadIdx.x + kOrderPer * kOrderThreads; t < n_tiles; t += kOrderThreads) atomicAdd(&hist[bin_of(tile_work[tile_base + t], t)], 1u);
-    __syncthreads();
-    {   // exclusive scan of the 4096 bins, 4 consecutive per thread
-        uint32_t c[4], mine = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { c[i] = hist[4 * threadIdx.x + i]; mine += c[i]; }
-        uint32_t inc = mine;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t u = (uint32_t)__shfl_up((int)inc, off);
-            if (lane >= off) inc += u;
-        }
-        if (lane == 63) sh_wave[wv] = inc;
-        __syncthreads();
-        uint32_t run = inc - mine;
-        for (int i = 0; i < wv; ++i) run += sh_wave[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { hist[4 * threadIdx.x + i] = run; run += c[i]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kOrderPer; ++i) {
-        const int t = threadIdx.x + i * kOrderThreads;
-        if (t < n_tiles) tile_order[hist[bin_of(w[i], t)] + slot[i]] = (uint32_t)t;
-    }
-    // frames of more than 8192 tiles: the rest goes behind its bin's register-held tiles, in the order the atomics land
-    __syncthreads();
-    if (n_tiles > kOrderPer * kOrderThreads) {
-#pragma unroll
-        for (int i = 0; i < kOrderPer; ++i) {           // advance every bin past the slots handed out above
-            const int t = threadIdx.x + i * kOrderThreads;
-            if (t < n_tiles) atomicAdd(&hist[bin_of(w[i], t)], 1u);
-        }
-        __syncthreads();
-        for (int t = threadIdx.x + kOrderPer * kOrderThreads; t < n_tiles; t += kOrderThreads)
-            tile_order[atomicAdd(&hist[bin_of(tile_work[tile_base + t], t)], 1u)] = (uint32_t)t;
-    }
+    tile_order_block<kOrderThreads, kOrderPer>(n_tiles, tile_base, tile_work, tile_order);
 }
-
 
 __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
                                                       const uint32_t *__restrict__ sorted_gid,
@@ -709,12 +634,12 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
 }
 
 int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, int sort_result, const GeomWS &gw, BinningWS &bw,
-                      const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s)
+                      const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s, bool order_ready)
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0 || chunks_run <= 0) return GSR_OK;
     static const bool in_tile_order = [] { const char *e = getenv("GSR_BWD_TILE_ORDER"); return e && atoi(e) != 0; }();
-    if (!in_tile_order) {
+    if (!in_tile_order && !order_ready) {
         ProfileScope prof("tile_order", s);
         if (n_tiles <= 8 * kOrderThreads)
             hipLaunchKernelGGL(k_tile_order<8>, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);

@@ -1324,3 +1324,45 @@ def test_backward_launch_order_is_a_permutation_longest_tile_first(W, H, P, rows
     shift = max(int(work.max()).bit_length() - 9, 0)
     along = work[order] >> shift
     assert np.all(along[1:] <= along[:-1])
+
+
+@pytest.mark.gpu
+def test_zero_fill_carries_the_backward_launch_order():
+    """A training frame (gradients wanted, sparse geometry backward, binning workspace guessed from the previous frame) runs as
+    ONE gsr_forward whose zero fill also sorts the tiles for K7 (k_zero_segments<true>, block 0): plan.tile_order_ready is set,
+    gsr_backward_render launches no k_tile_order, the order is a valid longest-first permutation and the screen-space
+    gradients equal, bit for bit, those of the same frame run without the early fill (its own k_tile_order launch)."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _native as N
+    W, H, P = 640, 368, 200_000
+    scene = S.make_scene(P, W, H, 1, 123)
+    kw = raster_kwargs(scene, S.make_camera(W, H))
+    rs, inp = _settings(kw), _inputs(kw, False)
+    args = (inp["means3D"], inp["shs"], None, inp["opacities"], inp["scales"], inp["rotations"], None, rs)
+    needs = (True, True, True, False, True, True, True, False)
+    g = S.make_grad_image(W, H, 6).to(DEV)
+    _, _, plain = dgr.rasterize_forward(*args)                                    # also leaves the workspace guess behind
+    want = dgr.rasterize_backward_screen(plain, g).clone()
+    assert plain.plan.tile_order_ready == 0
+    _, _, fr = dgr.rasterize_forward(*args, prepare_needs=needs)
+    assert int(fr.plan.chunk_rank_begin[fr.plan.chunks_run]) * 4 < P, "the scene must take the sparse path"
+    assert fr.pre is not None and fr.pre["grads"].prezeroed == 1 and fr.plan.tile_order_ready == 1
+    dgr.prepare_backward(fr, needs, screen_prefix_only=True)
+    N.profile_enable(True)
+    got = dgr.rasterize_backward_screen(fr, g)
+    torch.cuda.synchronize()
+    prof = N.profile_read(); N.profile_enable(False)
+    assert "render_bwd" in prof and "tile_order" not in prof, sorted(prof)
+    v = N.debug_views(fr.desc, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan)
+    n = ((W + 15) // 16) * ((H + 15) // 16)
+    order = v["tile_order"][:n].long().cpu().numpy()
+    assert sorted(order.tolist()) == list(range(n))
+    work = v["tile_work"].long().cpu().numpy()
+    shift = max(int(work.max()).bit_length() - 9, 0)
+    along = work[order] >> shift
+    assert work.max() > 0 and np.all(along[1:] <= along[:-1])
+    n_pref = int(fr.plan.chunk_rank_begin[fr.plan.chunks_run])
+    pref = N.frame_arrays(fr.desc, fr.geom_ws)[1][:n_pref].long()
+    assert torch.equal(got[pref], want[pref])                                     # (rows outside the binned prefix: never cleared here)
+    for t in fr.pre["tensors"] if fr.pre else ():                                # the early fill cleared every parameter gradient
+        assert t is None or float(t.abs().max()) == 0.0
