@@ -72,7 +72,7 @@ constexpr int kSelBins = 2048;           // bins per level
 constexpr int kSelShift1 = 20;           // level 1: key >> 20 (positive float bits < 2^31: 2040 bins in use, 8 per binade)
 constexpr int kSelShift2 = 9;            // level 2: the next 11 bits -> sub-bins of 512 key codes (6e-5 relative depth)
 constexpr int kSelRefine = 2;            // chunk boundaries refined at level 2: the ends of chunks 0 and 1
-constexpr int kSelBlocks = 256;
+constexpr int kSelBlocks = 1024;         // blocks of the partition kernels (the histogram kernels run 256: fewer flushes)
 // the chunk rule (see gsr_binning.hip's header): chunk c ends where the running optical mass passes
 // kChunkOpticalDepths x ln(1e4) per slab pixel x 4^c and the running tile count passes kMinFirstChunk x 4^c
 constexpr float kCutoffOpticalDepth = 9.2103404f;   // -ln(GSR_T_CUTOFF)

@@ -21,6 +21,7 @@
 namespace gsr {
 
 constexpr int kSelThreads = 512;
+constexpr int kSelHistBlocks = 256;
 constexpr int kSelWaves = kSelThreads / kWave;
 
 __device__ __forceinline__ uint32_t sel_bin1(uint32_t key) { const uint32_t b = key >> kSelShift1; return b < (uint32_t)kSelBins ? b : (uint32_t)kSelBins - 1u; }
@@ -344,12 +345,16 @@ int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s, 
     const double slab_px = (double)(f.ty1 - f.ty0) * GSR_TILE * (double)f.Gx * GSR_TILE;
     const unsigned long long first_mass =
         (unsigned long long)((double)kChunkOpticalDepths * kCutoffOpticalDepth * slab_px * (double)kMassUnitsPerPixelNeper) + 1ull;
+    // grid sizes, swept at 1e6 and 5e6 Gaussians: the histogram kernels are fastest with one block per CU (every block flushes
+    // the bins it touched with global atomics: 11 / 10.5 us at 256 blocks, 14.6 / 16.6 at 1024), the partition's scatter with
+    // four (12.3 -> 9.7 us; 53 -> 25 us at 5e6); the count pass does not care and must match the scatter
     int blocks = (f.P + kSelThreads * 4 - 1) / (kSelThreads * 4);
     if (blocks > kSelBlocks) blocks = kSelBlocks;
+    const int hist_blocks = blocks > kSelHistBlocks ? kSelHistBlocks : blocks;
     {
         ProfileScope prof("depth_hist", s);
-        hipLaunchKernelGGL(k_sel_hist<1>, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, first_mass, ws.sel);
-        hipLaunchKernelGGL(k_sel_hist<2>, dim3(blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, first_mass, ws.sel);
+        hipLaunchKernelGGL(k_sel_hist<1>, dim3(hist_blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, first_mass, ws.sel);
+        hipLaunchKernelGGL(k_sel_hist<2>, dim3(hist_blocks), dim3(kSelThreads), 0, s, f.P, ws.sort_keys[0], ws.tiles_mass, first_mass, ws.sel);
         GSR_LAUNCH_CHECK("depth_hist", debug, s);
     }
     {
