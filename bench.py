@@ -483,13 +483,24 @@ def _train_loop(workload, iters, dev, fused):
     train(gm, cams, targets, opt, pipe, bg, iterations=warm, scene_extent=6.0)
     with torch.no_grad():       # warm-up includes one full-size densification: the allocator has seen the grown tensors
         gm.densify_and_prune(opt.densify_grad_threshold, 0.005, 6.0, None)
+    gc.collect()                 # as in timed(): a full collection (48 ms over torch's import-time objects) is not the loop's cost
     torch.cuda.synchronize(dev)
     n0 = gm._xyz.shape[0]
+    _GC_LOG.clear()
+    stamps = []
+    stat0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
-    train(gm, cams, targets, opt, pipe, bg, iterations=warm + iters, first_iter=warm + 1, scene_extent=6.0)
+    train(gm, cams, targets, opt, pipe, bg, iterations=warm + iters, first_iter=warm + 1, scene_extent=6.0,
+          on_iteration=lambda it, loss, g: stamps.append(time.perf_counter()))          # host time per iteration (no sync)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    return {"iterations": iters, "its_per_s": round(iters / dt, 2), "ms_per_it": round(1e3 * dt / iters, 3),
+    gc_ms = round(1e3 * sum(_GC_LOG), 2)
+    stat1 = torch.cuda.memory_stats(dev)
+    per_it = [1e3 * (b - a) for a, b in zip([t0] + stamps[:-1], stamps)]
+    slow = {str(warm + 1 + i): round(x, 1) for i, x in enumerate(per_it) if x > 20.0}
+    return {"iterations": iters, "its_per_s": round(iters / dt, 2), "ms_per_it": round(1e3 * dt / iters, 3), "gc_ms_in_window": gc_ms,
+            "host_ms_per_it_median": round(sorted(per_it)[len(per_it) // 2], 3), "iterations_over_20_ms": slow,
+            "device_allocations_in_window": int(stat1["num_device_alloc"] - stat0["num_device_alloc"]),
             "gaussians_start": int(n0), "gaussians_end": int(gm._xyz.shape[0]),
             "includes": "LR schedule, render, L1/D-SSIM, backward, densification stats, densify+prune every 100 it, Adam"}
 
