@@ -158,19 +158,32 @@ __global__ __launch_bounds__(kLBlock) void k_loss_fwd(int C, int H, int W, LossR
     const int hr = threadIdx.x / (kLT / kRowW), hc0 = (threadIdx.x % (kLT / kRowW)) * kRowW;
     if (row_item) {
         v2f ab[kRowW + 10];                                   // (a, b) of one staged pixel: the moments pair up as
-#pragma unroll                                                 // (E[a], E[b]) and (E[a^2], E[b^2]) -> v_pk_fma_f32
-        for (int i = 0; i < kRowW + 10; ++i) ab[i] = v2f{sa[hr][kLO + hc0 + i], sb[hr][kLO + hc0 + i]};
+                                                               // (E[a], E[b]) and (E[a^2], E[b^2]) -> v_pk_fma_f32
+        // The 18 staged values start at column 3 + 8 q of the row: read as SIX aligned 16-byte words per plane (columns 8 q ..
+        // 8 q + 23).  Single-float reads put a wave's 64 addresses (row pitch and 8 q are multiples of 4 floats) on 8 of the 32
+        // banks: an 8-way conflict on every one of them.
+        float ra[kRowW + 16], rb[kRowW + 16];
+#pragma unroll
+        for (int j = 0; j < (kRowW + 16) / 4; ++j) {
+            const float4 va = *reinterpret_cast<const float4 *>(&sa[hr][hc0 + 4 * j]);
+            const float4 vb = *reinterpret_cast<const float4 *>(&sb[hr][hc0 + 4 * j]);
+            ra[4 * j] = va.x; ra[4 * j + 1] = va.y; ra[4 * j + 2] = va.z; ra[4 * j + 3] = va.w;
+            rb[4 * j] = vb.x; rb[4 * j + 1] = vb.y; rb[4 * j + 2] = vb.z; rb[4 * j + 3] = vb.w;
+        }
+        v2f sq[kRowW + 10];                                   // (a^2, b^2) and a b of every staged pixel, once: three FMAs per tap
+        float pr[kRowW + 10];                                 // (four instructions per tap when the products are formed inside)
+#pragma unroll
+        for (int i = 0; i < kRowW + 10; ++i) { ab[i] = v2f{ra[kLO + i], rb[kLO + i]}; sq[i] = ab[i] * ab[i]; pr[i] = ab[i][0] * ab[i][1]; }
 #pragma unroll
         for (int o = 0; o < kRowW; ++o) {
             v2f s01 = {0.f, 0.f}, s23 = {0.f, 0.f};
             float s4 = 0.f;
 #pragma unroll
             for (int i = 0; i < 11; ++i) {
-                const v2f xy = ab[o + i];
-                const v2f gxy = win.g[i] * xy;
-                s01 += gxy;
-                s23 += gxy * xy;
-                s4 += gxy[0] * xy[1];
+                const float g = win.g[i];
+                s01 += g * ab[o + i];
+                s23 += g * sq[o + i];
+                s4 += g * pr[o + i];
             }
             m[0][o] = s01[0]; m[1][o] = s01[1]; m[2][o] = s23[0]; m[3][o] = s23[1]; m[4][o] = s4;
         }
@@ -288,14 +301,17 @@ __global__ __launch_bounds__(kLBlock) void k_loss_bwd(int C, int H, int W, LossR
     if (row_item) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            float v[kRowW + 10];
+            float v[kRowW + 16];                              // six aligned 16-byte reads (see k_loss_fwd): columns 8 q .. 8 q + 23
 #pragma unroll
-            for (int i = 0; i < kRowW + 10; ++i) v[i] = sm[pl][hr][kLO + hc0 + i];
+            for (int j = 0; j < (kRowW + 16) / 4; ++j) {
+                const float4 q4 = *reinterpret_cast<const float4 *>(&sm[pl][hr][hc0 + 4 * j]);
+                v[4 * j] = q4.x; v[4 * j + 1] = q4.y; v[4 * j + 2] = q4.z; v[4 * j + 3] = q4.w;
+            }
 #pragma unroll
             for (int o = 0; o < kRowW; ++o) {
                 float t = 0.f;
 #pragma unroll
-                for (int i = 0; i < 11; ++i) t += win.g[i] * v[o + i];
+                for (int i = 0; i < 11; ++i) t += win.g[i] * v[kLO + o + i];
                 m[pl][o] = t;
             }
         }
