@@ -167,7 +167,7 @@ def main():
         "host": {"bound_to_numa_node": bound[0] if bound else None, "cpus": len(os.sched_getaffinity(0))},
         "kernels": m["kernels"], "roofline": m["roofline"], "cpu_baseline": None,
     }
-    for k in ("torch_getters", "fused_activations", "getter_fusion", "reference_loss_composition"):
+    for k in ("native_getters", "torch_getters", "fused_activations", "getter_fusion", "reference_loss_composition"):
         if m.get(k) is not None:
             line[k] = m[k]
     if single and not args.no_secondary and args.workload == "cfg3":
@@ -183,7 +183,7 @@ def main():
         }
     if single and args.train_loop > 0:
         line["train_loop"] = _train_loop(args.workload, args.train_loop, dev, False)
-        line["train_loop"]["fused_activations"] = _train_loop(args.workload, args.train_loop, dev, True)
+        line["train_loop"]["native_getters"] = _train_loop(args.workload, args.train_loop, dev, True)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = _cpu_baseline(args.workload)
     print(json.dumps(line))
@@ -274,6 +274,16 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
         N.profile_enable(False)
     res = {}
     if extras:
+        # (2a) the timed pass renders this package's GaussianModel from its raw leaves (activations inside the kernels: render()'s
+        # default for that class); the same model through its native getters (one launch forward, one backward) beside it
+        pipe.fused_activations = False
+        el, _ = timed(steps, max(warmup, 1))
+        pipe.fused_activations = None
+        res["native_getters"] = {
+            "value": round(steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / steps, 4),
+            "what": "same step, same scene.GaussianModel, with render(..., pipe.fused_activations=False): exp / normalize / sigmoid as "
+                    "the model's native getters (csrc/gsr_activations.hip, one launch forward and one backward over all P) instead "
+                    "of inside the preprocess / geometry-backward kernels"}
         # (2b) the same step with the reference's torch getters (exp / normalize / sigmoid / cat and their autograd backward)
         active["m"] = store
         el, _ = timed(steps, max(warmup, 1))
@@ -286,11 +296,11 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
         # fused into the HIP kernels (pipe.fused_activations -> GaussianRasterizer.forward_raw)
         pipe.fused_activations = True
         el, _ = timed(steps, max(warmup, 1))
-        pipe.fused_activations = False
+        pipe.fused_activations = None
         res["fused_activations"] = {
             "value": round(steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / steps, 4),
-            "what": "same step, activations fused into preprocess / geometry-backward kernels (extension beyond the "
-                    "reference API: render(..., pipe.fused_activations=True)); same image and parameter gradients"}
+            "what": "the torch-getter store of (2b) with render(..., pipe.fused_activations=True): its raw tensors (features_dc and "
+                    "features_rest as two tensors) go into the kernels; same image and parameter gradients"}
         # (4) the SAME caller code as the timed pass with the rasterizer's opt-in FUSE_GETTERS
         import diff_gaussian_rasterization as _dgr
         _dgr.FUSE_GETTERS = True
@@ -444,7 +454,7 @@ def _frame_stats(model, cam, bg, pipe):
                 live=live, pairs_bwd=int(ncontrib.sum()), binned_ranks=binned)
 
 
-def _train_loop(workload, iters, dev, fused):
+def _train_loop(workload, iters, dev, native_getters):
     """BASELINE configs[2] taken literally: the full train.py loop (LR schedule, render, loss, backward,
     densification statistics, densify/prune every 100 iterations, Adam) starting from the workload's cloud, with
     target views rendered from a second cloud (seed 30) on 8 cameras of a small arc."""
@@ -479,7 +489,7 @@ def _train_loop(workload, iters, dev, fused):
         tiny.densify_and_prune(opt.densify_grad_threshold, 0.005, 6.0, None)
     del tiny
     pipe = Pipe()
-    pipe.fused_activations = bool(fused)
+    pipe.fused_activations = False if native_getters else None      # None: render()'s default for scene.GaussianModel (raw leaves)
     train(gm, cams, targets, opt, pipe, bg, iterations=warm, scene_extent=6.0)
     with torch.no_grad():       # warm-up includes one full-size densification: the allocator has seen the grown tensors
         gm.densify_and_prune(opt.densify_grad_threshold, 0.005, 6.0, None)

@@ -102,6 +102,9 @@ typedef struct gsr_gaussians {   /* arguments of GaussianRasterizer.forward (dev
      *   opacities = _opacity logits        -> sigmoid        scales    = _scaling log-scales -> exp
      *   rotations = _rotation quaternions  -> normalize      shs       = _features_dc   [P,1,3]
      *   shs_rest  = _features_rest [P, sh_coeffs - 1, 3] (the torch.cat of get_features); NULL iff sh_coeffs == 1
+     * raw == 2: the same activations, but the SH coefficients are ONE interleaved table, shs = [P, sh_coeffs, 3] exactly as in the
+     * activated case (shs_rest NULL; grads.shs is then [P, sh_coeffs, 3] too): a parameter store that keeps get_features as a
+     * single leaf needs no cat and no split.
      * colors_precomp and cov3D_precomp must be NULL.  The backward then returns gradients w.r.t. the raw
      * tensors (chain rule through the activations fused into gsr_backward_geom). */
     const float *shs_rest;
@@ -117,7 +120,7 @@ typedef struct gsr_grads {       /* outputs of the backward; any may be NULL (no
     float *scales;         /* [P,3]   */
     float *rotations;      /* [P,4]   */
     float *cov3D_precomp;  /* [P,6]   */
-    float *shs_rest;       /* [P,M-1,3] raw mode only (then shs is [P,1,3]) */
+    float *shs_rest;       /* [P,M-1,3] raw == 1 only (then shs is [P,1,3]) */
     int32_t prezeroed;     /* != 0: the caller has already zero-filled every non-NULL tensor above (gsr_backward_prepare);
                               the sparse path of gsr_backward_geom then skips its own fill */
 } gsr_grads;

@@ -103,13 +103,20 @@ static int validate_inputs(const gsr_frame_desc *d, const gsr_camera *c, const g
     if (d->P == 0) return GSR_OK;
     if (!g->means3D || !g->opacities) { set_error("means3D / opacities missing"); return GSR_ERR_INVALID_ARGUMENT; }
     if (g->raw) {
-        // raw-parameter mode (a14): _features_dc + _features_rest, log-scales, raw quaternions, opacity logits
-        if (!g->shs || !g->scales || !g->rotations || g->colors_precomp || g->cov3D_precomp || d->sh_coeffs < 1 ||
-            ((g->shs_rest == nullptr) != (d->sh_coeffs == 1))) {
+        // raw-parameter mode (a14): log-scales, raw quaternions, opacity logits; SH as _features_dc + _features_rest (raw == 1) or
+        // as one interleaved table (raw == 2)
+        const bool common = g->shs && g->scales && g->rotations && !g->colors_precomp && !g->cov3D_precomp && d->sh_coeffs >= 1;
+        if (g->raw == 1 && (!common || ((g->shs_rest == nullptr) != (d->sh_coeffs == 1)))) {
             set_error("raw mode needs shs (features_dc), shs_rest (features_rest, NULL iff sh_coeffs == 1), scales and rotations, "
                       "and neither colors_precomp nor cov3D_precomp");
             return GSR_ERR_INVALID_ARGUMENT;
         }
+        if (g->raw == 2 && (!common || g->shs_rest)) {
+            set_error("raw mode 2 needs shs (the interleaved [P,sh_coeffs,3] table), no shs_rest, scales and rotations, and neither "
+                      "colors_precomp nor cov3D_precomp");
+            return GSR_ERR_INVALID_ARGUMENT;
+        }
+        if (g->raw != 1 && g->raw != 2) { set_error("raw must be 0, 1 or 2"); return GSR_ERR_INVALID_ARGUMENT; }
     } else if (g->shs_rest) {
         set_error("shs_rest is only meaningful with raw != 0");
         return GSR_ERR_INVALID_ARGUMENT;

@@ -12,19 +12,21 @@ namespace gsr {
 
 constexpr int kGeomBlock = 256;
 
-// One Gaussian's inputs in registers.  RAW: the tensors are the optimizer's raw parameters and
-// the activations (exp / normalize / sigmoid, cat of the SH features) happen here, in registers.
-template <int DEG, bool RAW>
+// One Gaussian's inputs in registers.  RAW != 0: the tensors are the optimizer's raw parameters and
+// the activations (exp / normalize / sigmoid) happen here, in registers.  RAW == 1: the SH coefficients arrive as the reference's
+// two tensors (features_dc [P,1,3], features_rest [P,M-1,3]) and are joined in registers (its torch.cat); RAW == 2: they are ONE
+// interleaved table [P,M,3] (scene.GaussianModel's packed leaf), read and differentiated exactly like activated input.
+template <int DEG, int RAW>
 struct GaussIn {
     float p[3], sc[3], q[4], cv[6], opacity;
-    float shl[RAW ? 3 * (DEG + 1) * (DEG + 1) : 1];     // RAW: the [K,3] coefficients, features_dc ++ features_rest
-    const float *sh_global;   // !RAW: this Gaussian's [M,3] coefficients in the shs tensor (or null)
+    float shl[RAW == 1 ? 3 * (DEG + 1) * (DEG + 1) : 1];     // RAW == 1: the [K,3] coefficients, features_dc ++ features_rest
+    const float *sh_global;   // otherwise: this Gaussian's [M,3] coefficients in the shs tensor (or null)
     RawAct act;
     // what preprocess_one / geom_backward_one read; no pointer member aliases shl, so the array stays in registers
-    __device__ __forceinline__ const float *sh() const { if constexpr (RAW) return shl; else return sh_global; }
+    __device__ __forceinline__ const float *sh() const { if constexpr (RAW == 1) return shl; else return sh_global; }
 };
 
-template <int DEG, bool RAW>
+template <int DEG, int RAW>
 __device__ __forceinline__ void load_gaussian(int i, int M, const float *__restrict__ means, const float *__restrict__ scales,
                                               const float *__restrict__ rots, const float *__restrict__ covpre,
                                               const float *__restrict__ opac, const float *__restrict__ shs,
@@ -43,18 +45,22 @@ __device__ __forceinline__ void load_gaussian(int i, int M, const float *__restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) in.q[k] = in.act.q[k];
         in.opacity = in.act.opacity;
-        constexpr int K = (DEG + 1) * (DEG + 1);
-        if (with_sh) {                       // culled Gaussians never read their coefficients
+        if constexpr (RAW == 1) {
+            constexpr int K = (DEG + 1) * (DEG + 1);
+            if (with_sh) {                       // culled Gaussians never read their coefficients
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) in.shl[ch] = shs[3 * (size_t)i + ch];
-            const float *rest = shs_rest + (size_t)i * (M - 1) * 3;
+                for (int ch = 0; ch < 3; ++ch) in.shl[ch] = shs[3 * (size_t)i + ch];
+                const float *rest = shs_rest + (size_t)i * (M - 1) * 3;
 #pragma unroll
-            for (int k = 3; k < 3 * K; ++k) in.shl[k] = rest[k - 3];
+                for (int k = 3; k < 3 * K; ++k) in.shl[k] = rest[k - 3];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3 * K; ++k) in.shl[k] = 0.f;
+            }
+            in.sh_global = nullptr;
         } else {
-#pragma unroll
-            for (int k = 0; k < 3 * K; ++k) in.shl[k] = 0.f;
+            in.sh_global = shs ? shs + (size_t)i * M * 3 : nullptr;
         }
-        in.sh_global = nullptr;
     } else {
         if (covpre) {
 #pragma unroll
@@ -69,7 +75,7 @@ __device__ __forceinline__ void load_gaussian(int i, int M, const float *__restr
     }
 }
 
-template <int DEG, bool RAW, bool LAZY>
+template <int DEG, int RAW, bool LAZY>
 __global__ __launch_bounds__(kGeomBlock) void k_preprocess(FrameK f, const float *__restrict__ view,
                                                            const float *__restrict__ proj, const float *__restrict__ campos,
                                                            const float *__restrict__ means, const float *__restrict__ scales,
@@ -134,20 +140,23 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
                        g.colors_precomp, ws.records, ws.tiles_mass, ws.clamped, radii, ws.sort_keys[0],                 \
                        ws.sort_vals[0], prefilter_flag, reinterpret_cast<uint4 *>(ws.sel), (int)(sizeof(SelState) / 16))
     if (g.shs) {                  // colours from SH: lazily, per binned chunk
-        if (g.raw) GSR_PRE(0, true, true);
-        else GSR_PRE(0, false, true);
+        if (g.raw) GSR_PRE(0, 1, true);            // lazy colours: no coefficient is read here, the SH layout does not matter
+        else GSR_PRE(0, 0, true);
     } else {
-        GSR_PRE(0, false, false);  // precomputed colours are copied into the record here
+        GSR_PRE(0, 0, false);  // precomputed colours are copied into the record here
     }
 #undef GSR_PRE
     GSR_LAUNCH_CHECK("preprocess", debug, s);
     return GSR_OK;
 }
 
+// raw mode with the reference's two SH tensors (features_dc + features_rest): raw == 1.  raw == 2: one interleaved [P,M,3] table
+static inline bool raw_split_sh(const FrameK &f, const gsr_gaussians &g) { (void)f; return g.raw == 1; }
+
 // ---- A.6, lazily: SH colour (+ clamp flags) of the Gaussians of depth ranks [r0, r1) — one binned chunk — patched into
 // their splat records right before the chunk is blended.  On a depth-complex frame that is a few thousand Gaussians
 // instead of all the visible ones.
-template <int DEG, bool RAW>
+template <int DEG, int RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors(FrameK f, int r0, int r1, const uint32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ cnt_open,
                                                              const float *__restrict__ campos, const float *__restrict__ means,
@@ -162,7 +171,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors(FrameK f, int r0, i
     const float p[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
     constexpr int K = (DEG + 1) * (DEG + 1);
     float shl[3 * K];
-    if constexpr (RAW) {
+    if constexpr (RAW == 1) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) shl[ch] = shs[3 * (size_t)i + ch];
         const float *rest = shs_rest + (size_t)i * (f.M - 1) * 3;
@@ -199,7 +208,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors(FrameK f, int r0, i
 // index order, so a wave's 64 coefficient rows are one contiguous run, loaded with full 16-byte-per-lane coalescing into
 // LDS rows (a gather by depth rank reads 192-byte rows scattered over the tensor).  Invisible Gaussians (zeroed record)
 // are skipped.
-template <int DEG, bool RAW>
+template <int DEG, int RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors_all(FrameK f, const float *__restrict__ campos, const float *__restrict__ means,
                                                                  const float *__restrict__ shs, const float *__restrict__ shs_rest,
                                                                  float4 *__restrict__ records, uint8_t *__restrict__ clamped)
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors_all(FrameK f, const
     if (__ballot(visible) == 0ull) return;
     float *stage = sh_stage + wv * (64 * kRow);
     const int rowf = 3 * f.M;                                  // stored floats per Gaussian (>= 3 K)
-    if constexpr (RAW) {
+    if constexpr (RAW == 1) {
         for (int e = lane; e < n_rows * 3; e += 64) stage[(e / 3) * kRow + e % 3] = shs[(size_t)wave_first * 3 + e];
         if constexpr (K > 1) {
             const int row = rowf - 3;
@@ -276,19 +285,19 @@ int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussi
 #define GSR_CA(DEG, RAW)                                                                                                \
     hipLaunchKernelGGL((k_chunk_colors_all<DEG, RAW>), dim3(grid_all), dim3(kGeomBlock), 0, s, f, cam.campos, g.means3D, g.shs,  \
                        g.shs_rest, ws.records, ws.clamped)
-        if (g.raw) {
+        if (raw_split_sh(f, g)) {              // (no activations in this kernel: RAW only names the SH layout)
             switch (f.D) {
-                case 0: GSR_CA(0, true); break;
-                case 1: GSR_CA(1, true); break;
-                case 2: GSR_CA(2, true); break;
-                default: GSR_CA(3, true); break;
+                case 0: GSR_CA(0, 1); break;
+                case 1: GSR_CA(1, 1); break;
+                case 2: GSR_CA(2, 1); break;
+                default: GSR_CA(3, 1); break;
             }
         } else {
             switch (f.D) {
-                case 0: GSR_CA(0, false); break;
-                case 1: GSR_CA(1, false); break;
-                case 2: GSR_CA(2, false); break;
-                default: GSR_CA(3, false); break;
+                case 0: GSR_CA(0, 0); break;
+                case 1: GSR_CA(1, 0); break;
+                case 2: GSR_CA(2, 0); break;
+                default: GSR_CA(3, 0); break;
             }
         }
 #undef GSR_CA
@@ -299,19 +308,19 @@ int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussi
 #define GSR_CC(DEG, RAW)                                                                                             \
     hipLaunchKernelGGL((k_chunk_colors<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, r0, r1, ws.order, ws.cnt_open, cam.campos, \
                        g.means3D, g.shs, g.shs_rest, ws.records, ws.clamped)
-    if (g.raw) {
+    if (raw_split_sh(f, g)) {
         switch (f.D) {
-            case 0: GSR_CC(0, true); break;
-            case 1: GSR_CC(1, true); break;
-            case 2: GSR_CC(2, true); break;
-            default: GSR_CC(3, true); break;
+            case 0: GSR_CC(0, 1); break;
+            case 1: GSR_CC(1, 1); break;
+            case 2: GSR_CC(2, 1); break;
+            default: GSR_CC(3, 1); break;
         }
     } else {
         switch (f.D) {
-            case 0: GSR_CC(0, false); break;
-            case 1: GSR_CC(1, false); break;
-            case 2: GSR_CC(2, false); break;
-            default: GSR_CC(3, false); break;
+            case 0: GSR_CC(0, 0); break;
+            case 1: GSR_CC(1, 0); break;
+            case 2: GSR_CC(2, 0); break;
+            default: GSR_CC(3, 0); break;
         }
     }
 #undef GSR_CC
@@ -322,7 +331,7 @@ int launch_chunk_colors(const FrameK &f, const gsr_camera &cam, const gsr_gaussi
 // ---- K8 + K9: dL/d(screen-space quantities) -> dL/d(inputs) for Gaussians [g0, g1).
 __device__ __forceinline__ bool sh_wanted_or_read(const float *shs, int has_colpre) { return shs != nullptr && !has_colpre; }
 
-template <int DEG, bool RAW>
+template <int DEG, int RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g1, const float *__restrict__ view,
                                                          const float *__restrict__ proj, const float *__restrict__ campos,
                                                          const float *__restrict__ means, const float *__restrict__ scales,
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int rowf = 3 * M;                                       // floats per Gaussian incl. the DC triple
     float *my_row = sh_stage + wv * (64 * 49) + lane * (rowf + 1);
-    const bool sh_wanted = shs && (out.shs || (RAW && out.shs_rest));
+    const bool sh_wanted = shs && (out.shs || (RAW == 1 && out.shs_rest));
     // A Gaussian that no pixel accepted (occluded behind saturated tiles, or just too faint everywhere) has an
     // all-zero screen-space gradient; every output of A.10 is linear in it, so its rows are exact zeros and none
     // of its inputs need to be read.  In depth-complex scenes that is the vast majority of the visible set.
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
     const bool wave_live = __ballot(live) != 0ull;
     if (sh_wanted_or_read(shs, has_colpre) && wave_live && rowf > 0 && n_rows > 0) {
         float *stage_w = sh_stage + wv * (64 * 49);
-        if constexpr (RAW) {
+        if constexpr (RAW == 1) {
             for (int e = lane; e < n_rows * 3; e += 64) stage_w[(e / 3) * (rowf + 1) + e % 3] = shs[(size_t)wave_first * 3 + e];
             const int row = rowf - 3;
             if (row > 0) {
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         const float *stage = sh_stage + wv * (64 * 49);
-        if constexpr (RAW) {
+        if constexpr (RAW == 1) {
             if (in_range && out.shs) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) out.shs[3 * (size_t)i + ch] = any_live ? my_row[ch] : 0.f;
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
 // ---- sparse variant for depth-complex frames: every output was zero-filled by memset; only the Gaussians of the
 // binned depth prefix (rank < n_ranks) can have a non-zero screen-space gradient.  One thread per rank, rows
 // written individually (they are few).
-template <int DEG, bool RAW>
+template <int DEG, int RAW>
 __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_ranks, const uint32_t *__restrict__ order,
                                                                 const float *__restrict__ view, const float *__restrict__ proj,
                                                                 const float *__restrict__ campos, const float *__restrict__ means,
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
         for (int k = 0; k < 6; ++k) out.cov3D_precomp[6 * (size_t)i + k] = g.dcov[k];
     }
     constexpr int K3 = 3 * (DEG + 1) * (DEG + 1);
-    if constexpr (RAW) {
+    if constexpr (RAW == 1) {
         if (out.shs) { out.shs[3 * (size_t)i] = dsh[0]; out.shs[3 * (size_t)i + 1] = dsh[1]; out.shs[3 * (size_t)i + 2] = dsh[2]; }
         if (out.shs_rest) {
             float *dst = out.shs_rest + (size_t)i * (M - 1) * 3;
@@ -585,8 +594,9 @@ int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, 
     if (g.colors_precomp) add(out.colors_precomp, P * 3);
     if (!g.cov3D_precomp) { add(out.scales, P * 3); add(out.rotations, P * 4); }
     if (g.cov3D_precomp) add(out.cov3D_precomp, P * 6);
-    if (g.shs) add(out.shs, P * 3 * (size_t)(g.raw ? 1 : f.M));
-    if (g.raw && f.M > 1) add(out.shs_rest, P * 3 * (size_t)(f.M - 1));
+    const bool split = raw_split_sh(f, g);
+    if (g.shs) add(out.shs, P * 3 * (size_t)(split ? 1 : f.M));
+    if (split && f.M > 1) add(out.shs_rest, P * 3 * (size_t)(f.M - 1));
     if (z.n == 0) return GSR_OK;
     const size_t total = z.end[z.n - 1];
     size_t blocks = (total / 4 + kGeomBlock - 1) / kGeomBlock / 4 + 1;
@@ -622,20 +632,10 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
                        cam.projmatrix, cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs,      \
                        g.shs_rest, g.colors_precomp ? 1 : 0, radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads),   \
                        out)
-            if (g.raw) {
-                switch (f.D) {
-                    case 0: GSR_GS(0, true); break;
-                    case 1: GSR_GS(1, true); break;
-                    case 2: GSR_GS(2, true); break;
-                    default: GSR_GS(3, true); break;
-                }
-            } else {
-                switch (g.shs ? f.D : 0) {
-                    case 0: GSR_GS(0, false); break;
-                    case 1: GSR_GS(1, false); break;
-                    case 2: GSR_GS(2, false); break;
-                    default: GSR_GS(3, false); break;
-                }
+            switch ((!g.raw ? 0 : (raw_split_sh(f, g) ? 1 : 2)) * 4 + (f.D > 3 ? 3 : (f.D < 0 ? 0 : f.D))) {
+                case 0: GSR_GS(0, 0); break;  case 1: GSR_GS(1, 0); break;  case 2: GSR_GS(2, 0); break;  case 3: GSR_GS(3, 0); break;
+                case 4: GSR_GS(0, 1); break;  case 5: GSR_GS(1, 1); break;  case 6: GSR_GS(2, 1); break;  case 7: GSR_GS(3, 1); break;
+                case 8: GSR_GS(0, 2); break;  case 9: GSR_GS(1, 2); break;  case 10: GSR_GS(2, 2); break; default: GSR_GS(3, 2); break;
             }
 #undef GSR_GS
         }
@@ -648,20 +648,10 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
     hipLaunchKernelGGL((k_geom_bwd<DEG, RAW>), dim3(grid), dim3(kGeomBlock), 0, s, f, g0, g1, cam.viewmatrix, cam.projmatrix, \
                        cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs, g.shs_rest,         \
                        g.colors_precomp ? 1 : 0, radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads), out)
-    if (g.raw) {
-        switch (f.D) {
-            case 0: GSR_GB(0, true); break;
-            case 1: GSR_GB(1, true); break;
-            case 2: GSR_GB(2, true); break;
-            default: GSR_GB(3, true); break;
-        }
-    } else {
-        switch (g.shs ? f.D : 0) {
-            case 0: GSR_GB(0, false); break;
-            case 1: GSR_GB(1, false); break;
-            case 2: GSR_GB(2, false); break;
-            default: GSR_GB(3, false); break;
-        }
+    switch ((!g.raw ? 0 : (raw_split_sh(f, g) ? 1 : 2)) * 4 + (f.D > 3 ? 3 : (f.D < 0 ? 0 : f.D))) {
+        case 0: GSR_GB(0, 0); break;  case 1: GSR_GB(1, 0); break;  case 2: GSR_GB(2, 0); break;  case 3: GSR_GB(3, 0); break;
+        case 4: GSR_GB(0, 1); break;  case 5: GSR_GB(1, 1); break;  case 6: GSR_GB(2, 1); break;  case 7: GSR_GB(3, 1); break;
+        case 8: GSR_GB(0, 2); break;  case 9: GSR_GB(1, 2); break;  case 10: GSR_GB(2, 2); break; default: GSR_GB(3, 2); break;
     }
 #undef GSR_GB
     GSR_LAUNCH_CHECK("geom_bwd", debug, s);

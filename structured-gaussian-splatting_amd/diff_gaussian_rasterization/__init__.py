@@ -130,19 +130,25 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
     scales, rotations, cov3D_precomp = _f32c(scales, device), _f32c(rotations, device), _f32c(cov3D_precomp, device)
     sh_rest = _f32c(sh_rest, device)
     M = int(sh.shape[1]) if sh is not None else 0
+    raw = int(raw)                   # 0: activated inputs; 1: raw, SH as features_dc + features_rest; 2: raw, SH as one [P,M,3] table
     if raw:
-        if sh is None or M != 1 or scales is None or rotations is None or colors_precomp is not None or cov3D_precomp is not None:
-            raise ValueError("raw mode takes features_dc [P,1,3], features_rest [P,M-1,3], log-scales and raw rotations")
-        M = 1 + (int(sh_rest.shape[1]) if sh_rest is not None else 0)
+        if sh is None or scales is None or rotations is None or colors_precomp is not None or cov3D_precomp is not None:
+            raise ValueError("raw mode takes SH coefficients, log-scales and raw rotations (no precomputed colours / covariances)")
+        if raw == 1:
+            if M != 1:
+                raise ValueError("raw mode takes features_dc [P,1,3], features_rest [P,M-1,3], log-scales and raw rotations")
+            M = 1 + (int(sh_rest.shape[1]) if sh_rest is not None else 0)
+        elif raw != 2 or sh_rest is not None:
+            raise ValueError("raw=2 takes the interleaved SH table [P,M,3] as `sh` and no sh_rest")
     fr = _Frame()
     fr.device, fr.M = device, M
     fr.desc = N.make_desc(P, int(rs.sh_degree), M, W, H, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.prefiltered,
                           rs.debug, tile_rows)
     fr.cam, cam_keep = _camera(rs, device)
     fr.gauss = N.Gaussians(N._ptr(means3D), N._ptr(sh), N._ptr(colors_precomp), N._ptr(opacities), N._ptr(scales),
-                           N._ptr(rotations), N._ptr(cov3D_precomp), N._ptr(sh_rest), 1 if raw else 0)
+                           N._ptr(rotations), N._ptr(cov3D_precomp), N._ptr(sh_rest), raw)
     fr.keep = (cam_keep, means3D, sh, colors_precomp, opacities, scales, rotations, cov3D_precomp, sh_rest)
-    fr.raw = bool(raw)
+    fr.raw = raw
     fr.pre = None
     geom_bytes, image_bytes = N.workspace_sizes(fr.desc)
     fr.geom_ws = _workspace(geom_bytes, device)
@@ -236,10 +242,10 @@ def _alloc_grads(fr: "_Frame", needs, alloc):
 
     def mk(flag, present, *shape):
         return alloc(*shape, dtype=torch.float32, device=dev) if (flag and present) else None
-    t = (mk(needs[0], True, P, 3), mk(needs[1], True, P, 3), mk(needs[2], sh is not None, P, 1 if fr.raw else M, 3),
+    t = (mk(needs[0], True, P, 3), mk(needs[1], True, P, 3), mk(needs[2], sh is not None, P, 1 if fr.raw == 1 else M, 3),
          mk(needs[3], colors_precomp is not None, P, 3), mk(needs[4], True, P, 1), mk(needs[5], scales is not None, P, 3),
          mk(needs[6], rotations is not None, P, 4), mk(needs[7], cov3D_precomp is not None, P, 6),
-         mk(fr.raw and len(needs) > 8 and needs[8], sh_rest is not None, P, M - 1, 3))
+         mk(fr.raw == 1 and len(needs) > 8 and needs[8], sh_rest is not None, P, M - 1, 3))
     grads = N.Grads(N._ptr(t[0]), N._ptr(t[1]), N._ptr(t[2]), N._ptr(t[3]), N._ptr(t[4]), N._ptr(t[5]), N._ptr(t[6]),
                     N._ptr(t[7]), N._ptr(t[8]), 0)
     return t, grads
@@ -411,8 +417,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         rs = raster_settings
         n = ctx.needs_input_grad       # xyz, means2D, f_dc, f_rest, opacity, scales, rotations
         needs = (n[0], n[1], n[2], False, n[4], n[5], n[6], False, n[3])
+        # features_rest None: features_dc is the whole interleaved table [P,M,3] (scene.GaussianModel's packed leaf)
         color, radii, frame = rasterize_forward(xyz, features_dc, None, opacity_logits, log_scales, raw_rotations, None, rs,
-                                                sh_rest=features_rest, raw=True, prepare_needs=None if rs.debug else needs)
+                                                sh_rest=features_rest, raw=2 if features_rest is None else 1,
+                                                prepare_needs=None if rs.debug else needs)
         if rs.debug:
             torch.cuda.synchronize(xyz.device)
         prepare_backward(frame, needs, screen_prefix_only=True)
@@ -565,6 +573,7 @@ class GaussianRasterizer(nn.Module):
         same gradients on the raw parameters as autograd through those getters, to fp32 rounding."""
         rs = self.raster_settings
         rs = rs._replace(sh_degree=int(rs.sh_degree), image_height=int(rs.image_height), image_width=int(rs.image_width))
-        if features_rest is None or features_rest.numel() == 0:
+        packed = features_rest is None and features_dc.dim() == 3 and features_dc.shape[1] > 1      # one [P,M,3] table
+        if not packed and (features_rest is None or features_rest.numel() == 0):
             features_rest = torch.empty(0, dtype=torch.float32, device=xyz.device)
         return _apply(_RasterizeGaussiansRaw, xyz, means2D, features_dc, features_rest, opacity_logits, log_scales, raw_rotations, rs)

@@ -54,4 +54,4 @@ class Pipe:
     convert_SHs_python = False
     compute_cov3D_python = False
     debug = False
-    fused_activations = False      # extension: see gaussian_renderer.render
+    fused_activations = None       # extension, see gaussian_renderer.render: None = only for this package's scene.GaussianModel

@@ -74,11 +74,18 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     # freeze flags (scene/gaussian_model.py:104-125 detach() the getter's result): a model with any of them set takes the
     # plain path, where a frozen parameter receives no gradient
     frozen = any(getattr(pc, f, False) for f in ("freeze_means", "freeze_scales", "freeze_rotations", "freeze_opacities"))
-    if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.compute_cov3D_python
-            and not pipe.convert_SHs_python and hasattr(pc, "_features_rest") and not frozen
-            and not getattr(pc, "packed_features", False)):      # scene.GaussianModel: its getters are already native
-        rendered_image, radii = rasterizer.forward_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest,
-                                                       pc._opacity, pc._scaling, pc._rotation)
+    packed = bool(getattr(pc, "packed_features", False))          # scene.GaussianModel: get_features is ONE interleaved leaf [P,M,3]
+    fused = getattr(pipe, "fused_activations", None)
+    if fused is None:            # not set: this package's own model renders from its raw leaves, any other store through its getters
+        fused = packed
+    if (fused and override_color is None and not pipe.compute_cov3D_python and not pipe.convert_SHs_python and not frozen
+            and (packed or hasattr(pc, "_features_rest"))):
+        if packed:               # exp / normalize / sigmoid inside the kernels, the SH table as it is: no getter runs at all
+            rendered_image, radii = rasterizer.forward_raw(pc._xyz, screenspace_points, pc._features, None,
+                                                           pc._opacity, pc._scaling, pc._rotation)
+        else:
+            rendered_image, radii = rasterizer.forward_raw(pc._xyz, screenspace_points, pc._features_dc, pc._features_rest,
+                                                           pc._opacity, pc._scaling, pc._rotation)
         return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
                 "radii": radii}
 

@@ -124,29 +124,80 @@ def test_getters_share_one_evaluation_until_it_is_stale():
     assert not gm.get_rotation.requires_grad and gm.get_scaling.requires_grad
 
 
-def test_render_from_the_model_equals_render_from_the_reference_getters():
-    """render() over GaussianModel (native getters, get_features = the packed table) against render() over the plain store
-    whose getters are the reference's torch ops: same image, same gradients on the raw parameters."""
+@pytest.mark.parametrize("mode,P,W,H,active", [("native_getters", 6000, 200, 136, None), ("raw_leaves", 6000, 200, 136, None),
+                                               ("raw_leaves", 6000, 200, 136, 1), ("raw_leaves", 150_000, 480, 272, None)])
+def test_render_from_the_model_equals_render_from_the_reference_getters(mode, P, W, H, active):
+    """render() over GaussianModel against render() over the plain store whose getters are the reference's torch ops: same
+    image, same gradients on the raw parameters.  native_getters (pipe.fused_activations = False): the model's one-launch
+    getters, bit-equal activations, so radii are equal and pixels agree to 2e-6.  raw_leaves (render()'s default for this class):
+    exp / normalize / sigmoid inside the preprocess and geometry-backward kernels, the SH table [P,M,3] as it is (raw = 2) —
+    an exp that differs in the last bit can move a radius across a ceil() or flip one blend decision, hence the looser pixel
+    bounds; a lower active degree leaves exact zeros above it; the 150 k-Gaussian frame saturates (sparse geometry backward,
+    early zero fill)."""
     from gaussian_params import Pipe
     from gaussian_renderer import render
-    W, H = 200, 136
-    gm, gp = _models(P=6000, W=W, H=H)
+    gm, gp = _models(P=P, W=W, H=H)
+    if active is not None:
+        gm.active_sh_degree = gp.active_sh_degree = active
     cam, bg = S.make_camera(W, H).to(DEV), torch.tensor([0.1, 0.2, 0.3], device=DEV)
     gimg = S.make_grad_image(W, H, 5).to(DEV)
     outs = []
     for m in (gm, gp):
-        out = render(cam, m, Pipe(), bg)
-        out["render"].backward(gimg)
+        pipe = Pipe()
+        if mode == "native_getters":
+            pipe.fused_activations = False
+        for _ in range(2):                     # the second frame runs as one gsr_forward (workspace guess, early zero fill)
+            for p in m.parameters() if hasattr(m, "parameters") else m._t.values():
+                p.grad = None
+            out = render(cam, m, pipe, bg)
+            out["render"].backward(gimg)
         outs.append(out)
     a, b = outs
-    assert torch.equal(a["radii"], b["radii"])
-    assert (a["render"] - b["render"]).abs().max() <= 2e-6
-    assert (a["viewspace_points"].grad - b["viewspace_points"].grad).abs().max() <= 1e-5 * float(b["viewspace_points"].grad.abs().max())
+    if mode == "native_getters":
+        assert torch.equal(a["radii"], b["radii"])
+        assert (a["render"] - b["render"]).abs().max() <= 2e-6
+        rel = 2e-5
+    else:
+        assert int((a["radii"] != b["radii"]).sum()) <= 2
+        derr = (a["render"] - b["render"]).detach().abs().amax(0)
+        assert float((derr > 2e-5).float().mean()) <= 1e-4 and float(derr.max()) <= 8e-3
+        rel = None
+    # (a flipped blend decision on a saturating frame moves a few Gaussians' gradients by whole contributions)
+    norm_tol = 1e-4 if P < 100_000 else 2e-3
+    va, vb = a["viewspace_points"].grad, b["viewspace_points"].grad
+    assert float((va - vb).norm() / vb.norm()) <= norm_tol
     pairs = (("_xyz", gm._xyz.grad, gp._xyz.grad), ("_scaling", gm._scaling.grad, gp._scaling.grad),
              ("_rotation", gm._rotation.grad, gp._rotation.grad), ("_opacity", gm._opacity.grad, gp._opacity.grad),
              ("_features_dc", gm._features.grad[:, :1], gp._features_dc.grad), ("_features_rest", gm._features.grad[:, 1:], gp._features_rest.grad))
     for name, x, y in pairs:
-        assert (x - y).abs().max() <= 2e-5 * float(y.abs().max()) + 1e-9, (name, float((x - y).abs().max()), float(y.abs().max()))
+        if rel is not None:
+            assert (x - y).abs().max() <= rel * float(y.abs().max()) + 1e-9, (name, float((x - y).abs().max()), float(y.abs().max()))
+        else:
+            x2, y2 = x.reshape(x.shape[0], -1), y.reshape(y.shape[0], -1)
+            scale = float(y2.abs().max())
+            bad = ((x2 - y2).abs() > 2e-5 * scale + 2e-3 * y2.abs()).any(1)
+            assert float(bad.float().mean()) <= 2e-4, (name, int(bad.sum()))
+            assert float((x2 - y2).norm() / y2.norm()) <= norm_tol, name
+    if active is not None:
+        K = (active + 1) ** 2
+        assert float(gm._features.grad[:, K:].abs().max()) == 0.0 and float(gm._features.grad[:, :K].abs().max()) > 0.0
+    if mode == "raw_leaves":
+        # the same kernels with the SH coefficients as the reference's two tensors (raw = 1): the packed table (raw = 2) must give
+        # the same pixels bit for bit, and the same gradients up to how the compiler contracts the SH polynomial when the
+        # coefficients sit in registers (raw = 1) or behind a pointer (raw = 2)
+        for p in gp.parameters():
+            p.grad = None
+        pipe = Pipe()
+        pipe.fused_activations = True
+        c = render(cam, gp, pipe, bg)
+        c["render"].backward(gimg)
+        assert torch.equal(a["render"], c["render"]) and torch.equal(a["radii"], c["radii"])
+        assert torch.equal(a["viewspace_points"].grad, c["viewspace_points"].grad)
+        for name, x, y in (("_xyz", gm._xyz.grad, gp._xyz.grad), ("_scaling", gm._scaling.grad, gp._scaling.grad),
+                           ("_rotation", gm._rotation.grad, gp._rotation.grad), ("_opacity", gm._opacity.grad, gp._opacity.grad),
+                           ("_features_dc", gm._features.grad[:, :1], gp._features_dc.grad),
+                           ("_features_rest", gm._features.grad[:, 1:], gp._features_rest.grad)):
+            assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()), name
 
 
 @pytest.mark.parametrize("M", [16, 9, 4, 1])
