@@ -4,10 +4,11 @@ selection (`pipe.compute_cov3D_python`, `pipe.convert_SHs_python`, `override_col
 with the reference GaussianModel's getters (get_xyz, get_opacity, get_scaling, get_rotation,
 get_features, get_covariance, active_sh_degree, max_sh_degree).
 
-Extension: `pipe.fused_activations = True` (not a reference flag; default off) renders from
-the model's raw parameters `_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation` with the
-activations fused into the HIP kernels (GaussianRasterizer.forward_raw) — same image, same gradients on the
-parameters, without the ~30 torch kernels of the getters and their backward.
+Extension: `pipe.fused_activations` (not a reference flag).  True: render from the model's raw parameters
+`_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation` with the activations fused into the HIP kernels
+(GaussianRasterizer.forward_raw) — same image, same gradients on the parameters, without the ~30 torch kernels of the getters
+and their backward.  Unset (None, the default): that path for this package's scene.GaussianModel (whose SH coefficients are
+one interleaved leaf `_features`: raw mode 2), the getters for any other store.  False: always the getters.
 """
 import math
 
