@@ -191,11 +191,13 @@ class _Comm:
 
 class _ShardedRasterize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, shard, sh_rest=None):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, shard, sh_rest=None,
+                packed_raw=False):
         # sh_rest given = raw-parameter mode (SURVEY a14 fused): sh is _features_dc, sh_rest _features_rest, opacities /
-        # scales / rotations the raw parameters; the activations run inside the kernels on every rank
+        # scales / rotations the raw parameters; the activations run inside the kernels on every rank.  packed_raw: the same with
+        # the SH coefficients as ONE interleaved table in `sh` (scene.GaussianModel's leaf; raw mode 2 of the ABI)
         comm, backend = shard.comm, shard.backend
-        raw = sh_rest is not None
+        raw = 2 if packed_raw else (1 if sh_rest is not None else 0)
         ctx.raw = raw
         H, W = int(rs.image_height), int(rs.image_width)
         Gy = (H + 15) // 16
@@ -210,7 +212,7 @@ class _ShardedRasterize(torch.autograd.Function):
         slab = (ty0, ty1) if ty1 > ty0 else (Gy, Gy)
         if raw:
             color, radii, frame = backend.forward(means3D, sh, None, opacities, scales, rotations, None, rs, slab, full,
-                                                  sh_rest=sh_rest, raw=True)
+                                                  sh_rest=sh_rest, raw=raw)
         else:
             color, radii, frame = backend.forward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                                                   rs, slab, full)
@@ -222,7 +224,7 @@ class _ShardedRasterize(torch.autograd.Function):
         mine = torch.empty(1, n_words + 4 + (Gy if balance else 0), dtype=full.dtype, device=full.device)
         if y1 > y0:
             mine[0, :n_words].view(3, rows_max, W)[:, :y1 - y0] = full[:, y0:y1]
-        needs = tuple(ctx.needs_input_grad[:8]) + ((bool(ctx.needs_input_grad[10]),) if raw else ())
+        needs = tuple(ctx.needs_input_grad[:8]) + ((bool(ctx.needs_input_grad[10]) and raw == 1,) if raw else ())
         ctx.needs = needs
         from . import caller_grad_enabled          # Function.forward itself runs with grad mode off
         want_prefix = shard.backward_mode == "allreduce_screen" and any(needs) and caller_grad_enabled()
@@ -311,7 +313,7 @@ class _ShardedRasterize(torch.autograd.Function):
         if g_means2D is not None:
             g_means2D = g_means2D.reshape(ctx.shapes[0])
         ctx.frame = None
-        return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None, None, g_rest
+        return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, None, None, g_rest, None
 
 
 class ShardedRenderer:
@@ -405,7 +407,19 @@ class ShardedRenderer:
             projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
             campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
         frozen = any(getattr(pc, f, False) for f in ("freeze_means", "freeze_scales", "freeze_rotations", "freeze_opacities"))
-        if (getattr(pipe, "fused_activations", False) and override_color is None and not pipe.compute_cov3D_python
+        packed = bool(getattr(pc, "packed_features", False))
+        fused = getattr(pipe, "fused_activations", None)
+        if fused is None:                    # as gaussian_renderer.render: this package's own model renders from its raw leaves
+            fused = packed
+        if (fused and packed and override_color is None and not pipe.compute_cov3D_python
+                and not getattr(pipe, "convert_SHs_python", False) and isinstance(self.backend, NativeBackend) and not frozen):
+            rs = rs._replace(sh_degree=int(rs.sh_degree))
+            e = torch.empty(0, dtype=torch.float32, device=xyz.device)
+            from . import _apply
+            image, radii = _apply(_ShardedRasterize, pc._xyz, screenspace_points, pc._features, e, pc._opacity, pc._scaling,
+                                  pc._rotation, e, rs, self, None, True)
+            return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+        if (fused and not packed and override_color is None and not pipe.compute_cov3D_python
                 and not getattr(pipe, "convert_SHs_python", False) and hasattr(pc, "_features_rest") and pc._features_rest.numel()
                 and isinstance(self.backend, NativeBackend) and not frozen):      # frozen parameters: the getters' detach() must run
             rs = rs._replace(sh_degree=int(rs.sh_degree))

@@ -32,19 +32,25 @@ def _render(rank, world, mode, which="small"):
     scene, cam = _scene(which)
     Wd, Ht = cam.image_width, cam.image_height
     cam = cam.to(dev)
-    model = GaussianParams(scene.to(dev)).to(dev)
+    if mode == "packed":         # this package's GaussianModel: rendered from its raw leaves (raw mode 2), on one GPU and on the ranks
+        from scene import GaussianModel
+        model = GaussianModel(scene.sh_degree)
+        model.adopt_scene(scene, device=dev)
+    else:
+        model = GaussianParams(scene.to(dev)).to(dev)
     bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
     gt = torch.rand(3, Ht, Wd, generator=torch.Generator().manual_seed(77)).to(dev)
     loss_value = None
     pipe = Pipe()
-    pipe.fused_activations = mode == "fused"          # raw parameters into the kernels, on one GPU and on the ranks alike
+    if mode != "packed":
+        pipe.fused_activations = mode == "fused"      # raw parameters into the kernels, on one GPU and on the ranks alike
     if world == 1:
         out = render(cam, model, pipe, bg)
         if mode == "loss":
             loss = training_loss(out["render"], gt)
     else:
         from diff_gaussian_rasterization.sharded import ShardedRenderer
-        sr = ShardedRenderer(dist, world, rank, backward_mode="allreduce_screen" if mode in ("loss", "fused") else mode)
+        sr = ShardedRenderer(dist, world, rank, backward_mode="allreduce_screen" if mode in ("loss", "fused", "packed") else mode)
         out = sr.render(cam, model, pipe, bg)
         if mode == "loss":
             loss = sr.training_loss(out["render"], gt)
@@ -58,7 +64,7 @@ def _render(rank, world, mode, which="small"):
                means2D=out["viewspace_points"].grad.cpu().numpy())
     if loss_value is not None:
         res["loss"] = np.float64(loss_value)
-    res.update({n: p.grad.cpu().numpy() for n, p in model.named_parameters()})
+    res.update({n: p.grad.cpu().numpy() for n, p in (model._t.items() if mode == "packed" else model.named_parameters())})
     return res
 
 
@@ -97,7 +103,7 @@ def _assert_equal_single(results, want, world, tol=5e-6):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "allreduce_screen"), (3, "allreduce_screen"), (2, "reduce_scatter"), (3, "loss"),
-                                        (2, "fused")])
+                                        (2, "fused"), (2, "packed")])
 def test_native_slabs_in_separate_processes_equal_single_render(world, mode):
     results = _run_ranks(world, mode)
     _assert_equal_single(results, _render(0, 1, mode), world)
