@@ -124,9 +124,11 @@ def test_getters_share_one_evaluation_until_it_is_stale():
     assert not gm.get_rotation.requires_grad and gm.get_scaling.requires_grad
 
 
-@pytest.mark.parametrize("mode,P,W,H,active", [("native_getters", 6000, 200, 136, None), ("raw_leaves", 6000, 200, 136, None),
-                                               ("raw_leaves", 6000, 200, 136, 1), ("raw_leaves", 150_000, 480, 272, None)])
-def test_render_from_the_model_equals_render_from_the_reference_getters(mode, P, W, H, active):
+@pytest.mark.parametrize("mode,P,W,H,active,D", [("native_getters", 6000, 200, 136, None, 3), ("raw_leaves", 6000, 200, 136, None, 3),
+                                                 ("raw_leaves", 6000, 200, 136, 1, 3), ("raw_leaves", 150_000, 480, 272, None, 3),
+                                                 ("raw_leaves", 6000, 200, 136, None, 2), ("raw_leaves", 6000, 200, 136, None, 1),
+                                                 ("raw_leaves", 150_000, 480, 272, None, 2), ("raw_leaves", 6000, 200, 136, None, 0)])
+def test_render_from_the_model_equals_render_from_the_reference_getters(mode, P, W, H, active, D):
     """render() over GaussianModel against render() over the plain store whose getters are the reference's torch ops: same
     image, same gradients on the raw parameters.  native_getters (pipe.fused_activations = False): the model's one-launch
     getters, bit-equal activations, so radii are equal and pixels agree to 2e-6.  raw_leaves (render()'s default for this class):
@@ -136,7 +138,7 @@ def test_render_from_the_model_equals_render_from_the_reference_getters(mode, P,
     early zero fill)."""
     from gaussian_params import Pipe
     from gaussian_renderer import render
-    gm, gp = _models(P=P, W=W, H=H)
+    gm, gp = _models(P=P, W=W, H=H, D=D)            # D = 2: rows of 27 floats (no 16-byte alignment); D = 0: no rest columns at all
     if active is not None:
         gm.active_sh_degree = gp.active_sh_degree = active
     cam, bg = S.make_camera(W, H).to(DEV), torch.tensor([0.1, 0.2, 0.3], device=DEV)
@@ -168,7 +170,8 @@ def test_render_from_the_model_equals_render_from_the_reference_getters(mode, P,
     assert float((va - vb).norm() / vb.norm()) <= norm_tol
     pairs = (("_xyz", gm._xyz.grad, gp._xyz.grad), ("_scaling", gm._scaling.grad, gp._scaling.grad),
              ("_rotation", gm._rotation.grad, gp._rotation.grad), ("_opacity", gm._opacity.grad, gp._opacity.grad),
-             ("_features_dc", gm._features.grad[:, :1], gp._features_dc.grad), ("_features_rest", gm._features.grad[:, 1:], gp._features_rest.grad))
+             ("_features_dc", gm._features.grad[:, :1], gp._features_dc.grad)) + (
+                 (("_features_rest", gm._features.grad[:, 1:], gp._features_rest.grad),) if D > 0 else ())
     for name, x, y in pairs:
         if rel is not None:
             assert (x - y).abs().max() <= rel * float(y.abs().max()) + 1e-9, (name, float((x - y).abs().max()), float(y.abs().max()))
@@ -195,8 +198,8 @@ def test_render_from_the_model_equals_render_from_the_reference_getters(mode, P,
         assert torch.equal(a["viewspace_points"].grad, c["viewspace_points"].grad)
         for name, x, y in (("_xyz", gm._xyz.grad, gp._xyz.grad), ("_scaling", gm._scaling.grad, gp._scaling.grad),
                            ("_rotation", gm._rotation.grad, gp._rotation.grad), ("_opacity", gm._opacity.grad, gp._opacity.grad),
-                           ("_features_dc", gm._features.grad[:, :1], gp._features_dc.grad),
-                           ("_features_rest", gm._features.grad[:, 1:], gp._features_rest.grad)):
+                           ("_features_dc", gm._features.grad[:, :1], gp._features_dc.grad)) + (
+                               (("_features_rest", gm._features.grad[:, 1:], gp._features_rest.grad),) if D > 0 else ()):
             assert float((x - y).abs().max()) <= 2e-6 * float(y.abs().max()), name
 
 
