@@ -150,6 +150,16 @@ class _Comm:
         allr = self.all_gather(t)
         return max((int(k), int(m)) for k, m in allr.tolist())
 
+    def pinned_scratch(self, n: int, dtype) -> torch.Tensor:
+        """A pinned host vector of n elements from a ring of eight (the caller fills it and enqueues ONE non-blocking copy to
+        the device; eight frames later, long after that copy has run, the buffer comes round again)."""
+        ring = self._pinned.setdefault(("scratch", n, dtype), [])
+        if len(ring) < 8:
+            ring.append(torch.empty(n, dtype=dtype).pin_memory())
+            return ring[-1]
+        self._scratch_turn = getattr(self, "_scratch_turn", 0) + 1
+        return ring[self._scratch_turn % 8]
+
     def read_halves_later(self, halves: torch.Tensor):
         """halves [world, 4] = (key_end + 1 >> 16, key_end + 1 & 0xFFFF, n >> 16, n & 0xFFFF) per rank as floats: one copy to
         pinned memory + an event now; the returned callable waits for that event only and returns (largest key_end over
@@ -229,8 +239,17 @@ class _ShardedRasterize(torch.autograd.Function):
         from . import caller_grad_enabled          # Function.forward itself runs with grad mode off
         want_prefix = shard.backward_mode == "allreduce_screen" and any(needs) and caller_grad_enabled()
         keys, k_mine, n_mine = backend.binned_prefix(frame) if want_prefix else (None, -1, 0)
-        for j, v in enumerate(((int(k_mine) + 1) >> 16, (int(k_mine) + 1) & 0xFFFF, int(n_mine) >> 16, int(n_mine) & 0xFFFF)):
-            mine[0, n_words + j].fill_(float(v))            # (fills, not an H2D copy of a host tensor: that one waits for the stream)
+        halves = ((int(k_mine) + 1) >> 16, (int(k_mine) + 1) & 0xFFFF, int(n_mine) >> 16, int(n_mine) & 0xFFFF)
+        if mine.device.type == "cuda":
+            # one asynchronous copy from a recycled PINNED buffer (a copy from pageable memory waits for the stream; four scalar
+            # fills were four launches in the stretch where the host is what the stream waits for)
+            host4 = comm.pinned_scratch(4, mine.dtype)
+            for j, v in enumerate(halves):
+                host4[j] = float(v)
+            mine[0, n_words:n_words + 4].copy_(host4, non_blocking=True)
+        else:
+            for j, v in enumerate(halves):
+                mine[0, n_words + j].fill_(float(v))
         if balance:          # this rank's per-tile-row work rides along; the sum over ranks is next frames' slab weights
             mine[0, n_words + 4:] = backend.row_work(frame, (W + 15) // 16, Gy).to(mine.dtype)
         gathered = comm.all_gather(mine)                        # [world, 3 * rows_max * W + 4 (+ Gy)]
