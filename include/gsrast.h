@@ -219,6 +219,16 @@ int gsr_backward_geom_rows(const gsr_frame_desc *desc, const gsr_camera *cam, co
  * Either may be NULL (not wanted). */
 int gsr_frame_arrays(const gsr_frame_desc *desc, const void *geom_ws, const uint32_t **depth_keys, const uint32_t **depth_order);
 
+/* Multi-GPU gradient exchange (the "allreduce_screen" mode of sharded.py): after the ranks agreed on the largest
+ * chunk end any of them binned (key_max, a depth key; n_rows = how many visible Gaussians have key <= key_max: exact, every
+ * rank knows it), gather lists those Gaussians in index order (rows[n_rows]) and packs their 48-byte screen-gradient rows
+ * (packed[n_rows, 12]) for ONE all-reduce; scatter writes the summed rows back.  Every rank builds the same list: the keys
+ * do not depend on its slab.  Uses the frame's selection scratch inside geom_ws (idle after the forward). */
+int gsr_exchange_rows_gather(const gsr_frame_desc *desc, void *geom_ws, uint32_t key_max, const float *screen_grads, int32_t n_rows,
+                             int32_t *rows, float *packed, void *stream);
+int gsr_exchange_rows_scatter(const gsr_frame_desc *desc, int32_t n_rows, const int32_t *rows, const float *packed, float *screen_grads,
+                              void *stream);
+
 /* `_C.mark_visible`: present[i] = 1 iff Gaussian i passes the near-plane test (A.1). */
 int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                      uint8_t *present, void *stream);

@@ -574,6 +574,29 @@ int gsr_frame_arrays(const gsr_frame_desc *desc, const void *geom_ws, const uint
     return GSR_OK;
 }
 
+int gsr_exchange_rows_gather(const gsr_frame_desc *desc, void *geom_ws, uint32_t key_max, const float *screen_grads, int32_t n_rows,
+                             int32_t *rows, float *packed, void *stream)
+{
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (n_rows < 0 || !geom_ws || (n_rows > 0 && (!screen_grads || !rows || !packed))) {
+        set_error("gsr_exchange_rows_gather: bad argument");
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    const FrameK f = make_frame(*desc);
+    GeomWS gw = carve_geom(geom_ws, f.P);
+    return launch_rows_gather(f, gw, key_max, screen_grads, n_rows, rows, packed, desc->debug != 0, (hipStream_t)stream);
+}
+
+int gsr_exchange_rows_scatter(const gsr_frame_desc *desc, int32_t n_rows, const int32_t *rows, const float *packed, float *screen_grads,
+                              void *stream)
+{
+    int rc = validate(desc);
+    if (rc) return rc;
+    if (n_rows < 0 || (n_rows > 0 && (!rows || !packed || !screen_grads))) { set_error("gsr_exchange_rows_scatter: bad argument"); return GSR_ERR_INVALID_ARGUMENT; }
+    return launch_rows_scatter(n_rows, rows, packed, screen_grads, desc->debug != 0, (hipStream_t)stream);
+}
+
 int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
                      void *stream)
 {

@@ -368,6 +368,113 @@ int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s, 
 }
 
 
+// ---- 2b. multi-GPU gradient exchange (sharded.py): the Gaussians whose depth key is <= key_max — every Gaussian some rank
+// binned — in INDEX order, and their 48-byte screen-space gradient rows packed behind one another for the all-reduce.  Keys do
+// not depend on a rank's slab, so every rank builds the same list.  Two launches (count per block, then scatter with the
+// blocks before it summed in the prologue) instead of eight torch kernels (two compares, and, nonzero's scan, gather, ...).
+constexpr int kRowsThreads = 1024;
+__device__ __forceinline__ void rows_block_range(int P, int &lo, int &hi)
+{
+    int per = (P + (int)gridDim.x - 1) / (int)gridDim.x;
+    per = (per + kRowsThreads - 1) / kRowsThreads * kRowsThreads;
+    const long long l = (long long)blockIdx.x * per;
+    lo = l < P ? (int)l : P;
+    hi = l + per < P ? (int)(l + per) : P;
+}
+
+__global__ __launch_bounds__(kRowsThreads) void k_rows_count(int P, const uint32_t *__restrict__ keys, uint32_t key_max, uint32_t *__restrict__ blk_cnt)
+{
+    __shared__ uint32_t sh_n;
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    int lo, hi;
+    rows_block_range(P, lo, hi);
+    uint32_t mine = 0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += kRowsThreads) mine += keys[i] <= key_max ? 1u : 0u;      // invisible = 0xFFFFFFFF
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&sh_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = sh_n;
+}
+
+__global__ __launch_bounds__(kRowsThreads) void k_rows_gather(int P, const uint32_t *__restrict__ keys, uint32_t key_max,
+                                                              const uint32_t *__restrict__ blk_cnt, const float4 *__restrict__ screen,
+                                                              int n_rows, int32_t *__restrict__ rows, float4 *__restrict__ packed)
+{
+    __shared__ uint32_t sh_base, sh_w[kRowsThreads / kWave], sh_pre[kRowsThreads / kWave], sh_tot;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (wv == 0) {                                               // rows of the blocks in front of this one
+        uint32_t s = 0;
+        for (int b = lane; b < (int)blockIdx.x; b += kWave) s += blk_cnt[b];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += (uint32_t)__shfl_xor((int)s, off);
+        if (lane == 0) sh_base = s;
+    }
+    __syncthreads();
+    uint32_t run = sh_base;
+    int lo, hi;
+    rows_block_range(P, lo, hi);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int i0 = lo; i0 < hi; i0 += kRowsThreads) {
+        const int i = i0 + (int)threadIdx.x;
+        const bool take = i < hi && keys[i] <= key_max;
+        const unsigned long long m = __ballot(take);
+        if (lane == 0) sh_w[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < kRowsThreads / kWave; ++w) { sh_pre[w] = t; t += sh_w[w]; }
+            sh_tot = t;
+        }
+        __syncthreads();
+        if (take) {
+            const uint32_t r = run + sh_pre[wv] + (uint32_t)__popcll(m & below);
+            if ((int)r < n_rows) {
+                rows[r] = i;
+                packed[3 * (size_t)r] = screen[3 * (size_t)i]; packed[3 * (size_t)r + 1] = screen[3 * (size_t)i + 1];
+                packed[3 * (size_t)r + 2] = screen[3 * (size_t)i + 2];
+            }
+        }
+        run += sh_tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rows_scatter(int n_rows, const int32_t *__restrict__ rows, const float4 *__restrict__ packed,
+                                                      float4 *__restrict__ screen)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const size_t i = (size_t)rows[r];
+    screen[3 * i] = packed[3 * (size_t)r]; screen[3 * i + 1] = packed[3 * (size_t)r + 1]; screen[3 * i + 2] = packed[3 * (size_t)r + 2];
+}
+
+int launch_rows_gather(const FrameK &f, GeomWS &ws, uint32_t key_max, const float *screen, int n_rows, int32_t *rows, float *packed,
+                       bool debug, hipStream_t s)
+{
+    if (f.P == 0 || n_rows <= 0) return GSR_OK;
+    int blocks = (f.P + kRowsThreads * 4 - 1) / (kRowsThreads * 4);
+    if (blocks > kSelBlocks) blocks = kSelBlocks;              // blk_cnt[0] of the frame's selection scratch: idle after the forward
+    uint32_t *blk_cnt = &ws.sel->blk_cnt[0][0];
+    ProfileScope prof("exchange_rows", s);
+    hipLaunchKernelGGL(k_rows_count, dim3(blocks), dim3(kRowsThreads), 0, s, f.P, ws.sort_keys[0], key_max, blk_cnt);
+    hipLaunchKernelGGL(k_rows_gather, dim3(blocks), dim3(kRowsThreads), 0, s, f.P, ws.sort_keys[0], key_max, blk_cnt,
+                       reinterpret_cast<const float4 *>(screen), n_rows, rows, reinterpret_cast<float4 *>(packed));
+    GSR_LAUNCH_CHECK("exchange_rows(gather)", debug, s);
+    return GSR_OK;
+}
+
+int launch_rows_scatter(int n_rows, const int32_t *rows, const float *packed, float *screen, bool debug, hipStream_t s)
+{
+    if (n_rows <= 0) return GSR_OK;
+    ProfileScope prof("exchange_rows", s);
+    hipLaunchKernelGGL(k_rows_scatter, dim3((n_rows + 255) / 256), dim3(256), 0, s, n_rows, rows, reinterpret_cast<const float4 *>(packed),
+                       reinterpret_cast<float4 *>(screen));
+    GSR_LAUNCH_CHECK("exchange_rows(scatter)", debug, s);
+    return GSR_OK;
+}
+
 // ---- 3. sort of ONE chunk by (depth, index), when it is about to be binned.  Input: order[r0 .. r0 + n) = the chunk's
 // Gaussians in index order (the partition above); output: the same range in depth order and, beside it, the inclusive
 // scan of their tile counts (offs_full, relative to the chunk's first rank).

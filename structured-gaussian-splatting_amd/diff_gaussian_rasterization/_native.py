@@ -64,7 +64,7 @@ class DebugViews(C.Structure):
 
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess", "gsr_forward",
-           "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_backward_geom_rows", "gsr_frame_arrays", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
+           "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_backward_geom_rows", "gsr_frame_arrays", "gsr_exchange_rows_gather", "gsr_exchange_rows_scatter", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows", "gsr_loss_l1_backward",
            "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_adam_step_split", "gsr_densify_stats",
            "gsr_activations_forward", "gsr_activations_backward")
@@ -220,6 +220,21 @@ def frame_arrays(desc, geom_ws):
         base = geom_ws.data_ptr()
         offs = _frame_offsets[P] = (int(k.value) - base, int(o.value) - base)
     return tuple(geom_ws[o:o + 4 * P].view(torch.int32) for o in offs)
+
+
+def exchange_rows_gather(desc, geom_ws, key_max: int, screen, n_rows: int):
+    """(rows int32 [n_rows], packed float32 [n_rows, 12]): the Gaussians with depth key <= key_max in index order and their
+    screen-gradient rows, packed for one all-reduce."""
+    rows = torch.empty(n_rows, dtype=torch.int32, device=screen.device)
+    packed = torch.empty(n_rows, SCREEN_GRAD_STRIDE, dtype=torch.float32, device=screen.device)
+    _check(load().gsr_exchange_rows_gather(C.byref(desc), _ptr(geom_ws), C.c_uint32(int(key_max) & 0xFFFFFFFF), _ptr(screen), C.c_int32(n_rows),
+                                           _ptr(rows), _ptr(packed), _stream(screen.device)), "gsr_exchange_rows_gather")
+    return rows, packed
+
+
+def exchange_rows_scatter(desc, rows, packed, screen):
+    _check(load().gsr_exchange_rows_scatter(C.byref(desc), C.c_int32(rows.numel()), _ptr(rows), _ptr(packed), _ptr(screen),
+                                            _stream(screen.device)), "gsr_exchange_rows_scatter")
 
 
 def mark_visible(means3D, viewmatrix, projmatrix, present):

@@ -91,6 +91,18 @@ class NativeBackend:
             return rasterize_backward_geom(frame, screen, needs, g0, g1, binned_ranks=-1)
         return rasterize_backward_geom(frame, screen, needs, g0, g1, rows=rows.to(torch.int32))
 
+    def gather_rows(self, frame, k_max, n_max, partial):
+        """(idx int32 [n_max], packed [n_max, 12]): the Gaussians with 0 <= key <= k_max in index order and their rows of
+        `partial`, in two native launches (gsr_exchange_rows_gather)."""
+        from . import _native as N
+        with torch.cuda.device(partial.device):
+            return N.exchange_rows_gather(frame.desc, frame.geom_ws, k_max, partial, n_max)
+
+    def scatter_rows(self, frame, idx, packed, screen):
+        from . import _native as N
+        with torch.cuda.device(screen.device):
+            N.exchange_rows_scatter(frame.desc, idx, packed, screen)
+
     def prepare_backward(self, frame, needs):
         """Early zero fill of the backward's outputs (gsr_backward_prepare) while the stream waits for the all-gather."""
         from . import prepare_backward
@@ -300,9 +312,14 @@ class _ShardedRasterize(torch.autograd.Function):
                 screen = comm.all_reduce_sum(partial.contiguous())
             else:
                 screen = partial                                    # rows outside the set are zero on every rank
-                idx = torch.nonzero_static((keys >= 0) & (keys <= k_max), size=n_max).view(-1)      # n_max is exact: no host sync
-                if n_max > 0:
-                    screen[idx] = comm.all_reduce_sum(partial[idx].contiguous())       # in place: `partial` is not used again
+                if n_max > 0 and k_max >= 0 and hasattr(backend, "gather_rows") and partial.is_cuda and partial.is_contiguous():
+                    # native: the list and the packed rows in two launches, the summed rows written back in one
+                    idx, packed = backend.gather_rows(frame, k_max, n_max, partial)
+                    backend.scatter_rows(frame, idx, comm.all_reduce_sum(packed), screen)
+                else:
+                    idx = torch.nonzero_static((keys >= 0) & (keys <= k_max), size=n_max).view(-1)  # n_max is exact: no host sync
+                    if n_max > 0:
+                        screen[idx] = comm.all_reduce_sum(partial[idx].contiguous())   # in place: `partial` is not used again
             # (3) every rank runs the whole geometry backward: full parameter gradients, no further collective
             out = list(backend.backward_geom(frame, screen, needs, 0, P, idx))
         else:

@@ -276,3 +276,34 @@ def test_slab_balancer_moves_the_boundaries_and_keeps_the_result():
             w = p.grad.cpu().numpy()
             scale = max(np.abs(w).max(), 1e-30)
             assert np.abs(results[r]["grads"][n] - w).max() <= 5e-6 * scale, (r, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,frac", [(1, 1.0), (5000, 0.3), (300_000, 0.02), (4_500_000, 0.5)])
+def test_exchange_rows_gather_and_scatter_equal_the_torch_expression(P, frac):
+    """gsr_exchange_rows_gather / _scatter (the sharded backward's gradient exchange) against what they replace:
+    idx = nonzero((keys >= 0) & (keys <= k_max)) in index order, packed = partial[idx], screen[idx] = summed rows.  Keys are
+    written into a frame's geometry workspace by hand; 4.5 M Gaussians: more blocks than the 1024 per-block counters."""
+    from diff_gaussian_rasterization import _native as N
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(P)
+    desc = N.make_desc(P, 0, 1, 64, 64, 0.5, 0.5, 1.0, False, False)
+    geom_bytes, _ = N.workspace_sizes(desc)
+    geom_ws = torch.zeros(geom_bytes, dtype=torch.uint8, device=dev)
+    keys = N.frame_arrays(desc, geom_ws)[0]                       # int32 view [P] into the workspace
+    vals = torch.randint(0x3E4CCCCD, 0x40C00000, (P,), generator=g, dtype=torch.int64)
+    vals[torch.rand(P, generator=g) < 0.25] = 0xFFFFFFFF          # invisible
+    keys.copy_(vals.to(torch.int64).where(vals < 2 ** 31, vals - 2 ** 32).to(torch.int32).to(dev))
+    visible = vals[vals != 0xFFFFFFFF]
+    k_max = int(visible.sort().values[max(int(frac * visible.numel()) - 1, 0)]) if visible.numel() else 0x3E4CCCCD
+    partial = torch.randn(P, 12, generator=g).to(dev)
+    want_idx = torch.nonzero((keys >= 0) & (keys <= k_max)).view(-1)
+    n = int(want_idx.numel())
+    rows, packed = N.exchange_rows_gather(desc, geom_ws, k_max, partial, n)
+    torch.cuda.synchronize()
+    assert torch.equal(rows.long(), want_idx) and torch.equal(packed, partial[want_idx])
+    screen = torch.zeros_like(partial)
+    N.exchange_rows_scatter(desc, rows, packed * 2.0, screen)
+    want = torch.zeros_like(partial)
+    want[want_idx] = partial[want_idx] * 2.0
+    assert torch.equal(screen, want)
