@@ -149,6 +149,20 @@ class _Comm:
         self.dist.all_gather_into_tensor(out, shard.contiguous(), group=self.group)
         return out
 
+    def all_gather_begin(self, shard: torch.Tensor):
+        """all_gather in two halves: the collective is started here (on RCCL's own stream), the returned callable makes the
+        current stream wait for it and hands out the result — what the caller enqueues in between runs beside the transfer."""
+        if self.gloo or shard.device.type == "cpu":
+            out = self.all_gather(shard)
+            return lambda: out
+        out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        work = self.dist.all_gather_into_tensor(out, shard.contiguous(), group=self.group, async_op=True)
+
+        def finish():
+            work.wait()                    # stream-level wait (no host block)
+            return out
+        return finish
+
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.gloo and t.device.type != "cpu":
             return self.all_reduce_sum(t.cpu()).to(t.device)
@@ -264,7 +278,11 @@ class _ShardedRasterize(torch.autograd.Function):
                 mine[0, n_words + j].fill_(float(v))
         if balance:          # this rank's per-tile-row work rides along; the sum over ranks is next frames' slab weights
             mine[0, n_words + 4:] = backend.row_work(frame, (W + 15) // 16, Gy).to(mine.dtype)
-        gathered = comm.all_gather(mine)                        # [world, 3 * rows_max * W + 4 (+ Gy)]
+        gather_done = comm.all_gather_begin(mine)               # [world, 3 * rows_max * W + 4 (+ Gy)]
+        hook = getattr(backend, "prepare_backward", None)
+        if hook is not None and want_prefix:
+            hook(frame, needs)             # the backward's zero fill (50 us of stores) runs beside the slabs' transfer
+        gathered = gather_done()
         if balance:
             shard.set_row_work(gathered[:, n_words + 4:].sum(0))
         for r, (a, b) in enumerate(slabs):
@@ -277,9 +295,6 @@ class _ShardedRasterize(torch.autograd.Function):
             # widest binned depth prefix over the ranks: selects and sizes the backward's gradient exchange; on its way to
             # pinned host memory now, so that the backward finds it without a stream drain
             ctx.n_max = (keys, comm.read_halves_later(gathered[:, n_words:n_words + 4]) if keys is not None else None)
-            hook = getattr(backend, "prepare_backward", None)       # the native provider zero-fills the backward's outputs now
-            if hook is not None:
-                hook(frame, needs)
             # ... and the host picks the pair up HERE, behind the copies and the fill it has just enqueued (the stream is busy for
             # another ~50 us): waiting for it in the backward stalled the host until the whole forward + loss had drained, and every
             # launch of the backward then arrived late (0.39 ms of idle stream per step at world size 1).
