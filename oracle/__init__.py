@@ -5,4 +5,4 @@ import this package; the product (``structured-gaussian-splatting_amd/``) never 
 Parity status: see the header of ``oracle/gsr_oracle.c`` (sub-steps with an in-tree twin are
 pinned by ``tests/golden``; the rasterizer proper is "parity unpinned").
 """
-from .gsr_oracle import OracleFrame, build, rasterize, dist2_knn3, lib_path  # noqa: F401
+from .gsr_oracle import OracleFrame, OracleRawFrame, build, rasterize, rasterize_raw, dist2_knn3, lib_path  # noqa: F401

@@ -12,6 +12,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+FRAGILE_POS_ULPS = 2.0
 _LIB = None
 
 
@@ -134,7 +135,7 @@ class OracleFrame:
 
 def rasterize(*, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix, projmatrix,
               sh_degree, campos, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-              cov3D_precomp=None, dtype=np.float32, tile_rows=None, fragile_eps=2e-6,
+              cov3D_precomp=None, dtype=np.float32, tile_rows=None, fragile_eps=2e-6, fragile_pos=None,
               parallel=False) -> OracleFrame:
     """Forward pass.  Argument names mirror GaussianRasterizationSettings + GaussianRasterizer.forward
     (reference call site gaussian_renderer/__init__.py:36-49, 85-93).  `tile_rows=(ty0, ty1)` restricts
@@ -163,6 +164,8 @@ def rasterize(*, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier
     if shs is not None:
         assert (D + 1) ** 2 <= M, "active SH degree exceeds stored coefficients"
     ty0, ty1 = (-1, -1) if tile_rows is None else tile_rows
+    if fragile_pos is None:          # pixels: a splat's screen position in binary32 is good to a few ulps of the image size
+        fragile_pos = FRAGILE_POS_ULPS * 2.0 ** -24 * max(int(image_width), int(image_height))
     lib = _lib()
     bg_, view_, proj_, cam_ = arr(bg, (3,)), arr(viewmatrix, (16,)), arr(projmatrix, (16,)), arr(campos, (3,))
     op_ = arr(opacities, (P,)) if P else arr(np.zeros(0))
@@ -170,7 +173,7 @@ def rasterize(*, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier
     h = getattr(lib, f"gso_forward_{suf}")(
         C.c_int(P), C.c_int(D), C.c_int(M), C.c_int(int(image_width)), C.c_int(int(image_height)),
         C.c_double(float(tanfovx)), C.c_double(float(tanfovy)), C.c_double(float(scale_modifier)),
-        C.c_int(ty0), C.c_int(ty1), C.c_double(fragile_eps), C.c_int(int(parallel)),
+        C.c_int(ty0), C.c_int(ty1), C.c_double(fragile_eps), C.c_double(fragile_pos), C.c_int(int(parallel)),
         _ptr(bg_), _ptr(view_), _ptr(proj_), _ptr(cam_), _ptr(means3D), _ptr(shs), _ptr(args[0]), _ptr(op_),
         _ptr(args[1]), _ptr(args[2]), _ptr(args[3]))
     return OracleFrame(h, suf, dtype, P, D, M, int(image_width), int(image_height),
@@ -183,3 +186,51 @@ def dist2_knn3(xyz: np.ndarray) -> np.ndarray:
     out = np.zeros(xyz.shape[0], np.float32)
     _lib().gso_dist2_knn3(C.c_int(xyz.shape[0]), _ptr(xyz), _ptr(out))
     return out
+
+
+# ---- raw-leaves entry: the parameter store's activations in front of the rasterizer, their chain rule behind it -------------
+class OracleRawFrame:
+    """`rasterize_raw`'s result: the OracleFrame of the ACTIVATED inputs (binary64 activations of the raw leaves) plus what
+    the chain rule back to the raw leaves needs.  `backward()` returns gradients named like the leaves of the reference's
+    GaussianModel (scene/gaussian_model.py:47-55): _xyz, _features ([P,M,3]: _features_dc | _features_rest), _opacity,
+    _scaling, _rotation — and means2D (the `viewspace_points` gradient, gaussian_renderer/__init__.py:26-30)."""
+
+    def __init__(self, frame: OracleFrame, scales, rotations, opacities, raw_rotations, norm):
+        self.frame = frame
+        self._scales, self._rot, self._op, self._raw_rot, self._norm = scales, rotations, opacities, raw_rotations, norm
+
+    def __getattr__(self, name):                     # color, radii, fragile_px, xy, Gx, ... : the activated frame's
+        return getattr(self.frame, name)
+
+    def backward(self, dL_dcolor: np.ndarray, parallel: bool = False) -> dict:
+        act = self.frame.backward(dL_dcolor, parallel=parallel)
+        P = self.frame.P
+        # get_scaling = exp(_scaling)                      (scene/gaussian_model.py:101-104)
+        d_scaling = act["scales"] * self._scales
+        # get_opacity = sigmoid(_opacity)                  (:123-125)
+        d_opacity = act["opacities"].reshape(P, 1) * (self._op * (1.0 - self._op)).reshape(P, 1)
+        # get_rotation = normalize(_rotation) = q / max(|q|, 1e-12)   (:106-109): d/dq = (g - qhat (qhat . g)) / |q|
+        g = act["rotations"]
+        d_rotation = (g - self._rot * (self._rot * g).sum(1, keepdims=True)) / self._norm
+        # get_features = cat(_features_dc, _features_rest) (:116-120): the gradient of the table is dL/dshs itself
+        return {"_xyz": act["means3D"], "_features": act["shs"], "_opacity": d_opacity, "_scaling": d_scaling,
+                "_rotation": d_rotation, "means2D": act["means2D"], "screen": act["screen"], "activated": act}
+
+
+def rasterize_raw(*, means3D, features, opacity_logits, log_scales, raw_rotations, dtype=np.float64, **settings) -> OracleRawFrame:
+    """The rasterizer as the reference's training step reaches it (train.py:99 -> gaussian_renderer/__init__.py:53-93 with
+    `pipe.compute_cov3D_python = pipe.convert_SHs_python = False`): the raw leaves of the parameter store go through the
+    getters of scene/gaussian_model.py:101-125 — exp, normalize (torch.nn.functional.normalize: eps 1e-12), sigmoid, cat —
+    evaluated in `dtype` (binary64 by default), then through `rasterize`.  `features` is the [P, M, 3] table
+    (= cat(_features_dc, _features_rest, dim=1)); `settings` are rasterize's other keyword arguments."""
+    dt = np.dtype(dtype)
+    raw_s = np.asarray(log_scales, dt)
+    raw_q = np.asarray(raw_rotations, dt)
+    raw_o = np.asarray(opacity_logits, dt).reshape(-1, 1)
+    scales = np.exp(raw_s)
+    norm = np.maximum(np.sqrt((raw_q * raw_q).sum(1, keepdims=True)), 1e-12)
+    rotations = raw_q / norm
+    opacities = 1.0 / (1.0 + np.exp(-raw_o))
+    fr = rasterize(means3D=np.asarray(means3D, dt), shs=np.asarray(features, dt), opacities=opacities, scales=scales,
+                   rotations=rotations, dtype=dt, **settings)
+    return OracleRawFrame(fr, scales, rotations, opacities, raw_q, norm)

@@ -11,7 +11,7 @@
 typedef struct FN(ctx) {
     /* configuration */
     int P, D, M, W, H, Gx, Gy, ty0, ty1;
-    REAL tanfovx, tanfovy, focal_x, focal_y, scale_modifier, fragile_eps;
+    REAL tanfovx, tanfovy, focal_x, focal_y, scale_modifier, fragile_eps, fragile_pos;
     REAL bg[3], view[16], proj[16], campos[3];
     int has_cov_precomp, has_colors_precomp;
     /* inputs (owned copies) */
@@ -19,6 +19,8 @@ typedef struct FN(ctx) {
     /* per-Gaussian forward state (A.1-A.6) */
     int32_t *radii;
     REAL *xy, *depth, *cov3D, *conic_op, *rgb;
+    float *depth_lo, *depth_hi;  /* [P]: the binary32 view depth as evaluated without FMA, with FMA, and rounded from binary64: min / max */
+    REAL *kappa;                 /* [P]: (a c + b^2) / det of the 2D covariance: how much binary32 rounding of a, b, c is amplified in the conic */
     uint8_t *clamped;
     int32_t *rect;               /* xmin, ymin, xmax, ymax (tile units, slab-clipped in y) */
     uint32_t *tiles_touched;
@@ -50,7 +52,7 @@ void FN(free)(FN(ctx) *c)
     free(c->means3D); free(c->shs); free(c->colors_precomp); free(c->opacities);
     free(c->scales); free(c->rotations); free(c->cov3D_precomp);
     free(c->radii); free(c->xy); free(c->depth); free(c->cov3D); free(c->conic_op);
-    free(c->rgb); free(c->clamped); free(c->rect); free(c->tiles_touched);
+    free(c->rgb); free(c->kappa); free(c->depth_lo); free(c->depth_hi); free(c->clamped); free(c->rect); free(c->tiles_touched);
     free(c->keys); free(c->vals); free(c->ranges);
     free(c->color); free(c->final_T); free(c->n_contrib); free(c->fragile_px); free(c->fragile_g);
     free(c);
@@ -228,6 +230,19 @@ static void FN(preprocess)(FN(ctx) *c)
         c->xy[2 * i] = px; c->xy[2 * i + 1] = py;
         c->conic_op[4 * i] = cA; c->conic_op[4 * i + 1] = cB; c->conic_op[4 * i + 2] = cC;
         c->conic_op[4 * i + 3] = c->opacities[i];
+        c->kappa[i] = (a * cc + b * b) * R_FABS(det_inv);
+        {   /* the sort key is the binary32 view depth: three legitimate binary32 evaluations of it */
+            const float p0 = (float)p[0], p1 = (float)p[1], p2 = (float)p[2];
+            const float v2 = (float)V[2], v6 = (float)V[6], v10 = (float)V[10], v14 = (float)V[14];
+            volatile float m0 = p0 * v2, m1 = p1 * v6, m2 = p2 * v10;
+            volatile float s01 = m0 + m1;
+            volatile float s012 = s01 + m2;
+            const float dA = s012 + v14;
+            const float dB = fmaf(p2, v10, fmaf(p1, v6, m0)) + v14;
+            const float dC = (float)((double)p0 * v2 + (double)p1 * v6 + (double)p2 * v10 + (double)v14);
+            float lo_ = dA < dB ? dA : dB, hi_ = dA < dB ? dB : dA;
+            c->depth_lo[i] = lo_ < dC ? lo_ : dC; c->depth_hi[i] = hi_ > dC ? hi_ : dC;
+        }
         memcpy(c->rgb + 3 * i, rgb, sizeof rgb);
         memcpy(c->clamped + 3 * i, cl, 3);
         /* slab clip in tile rows (multi-GPU): radii stay those of the full image */
@@ -313,7 +328,10 @@ static void FN(render_tile)(FN(ctx) *c, int tx, int ty, int64_t *pairs_out)
         for (int px = tx * GSR_TILE; px < (tx + 1) * GSR_TILE && px < W; ++px) {
             REAL T = 1, C[3] = {0, 0, 0};
             int32_t contributor = 0, last = 0;
-            uint8_t fragile = 0;
+            uint8_t fragile = c->fragile_px[(size_t)py * W + px];      /* tile membership of a splat that reaches it is uncertain */
+            REAL terr = 0;
+            float prev_lo = 0, prev_hi = 0;
+            int prev_reaches = 0;
             for (int64_t j = start; j < end; ++j) {
                 ++contributor; ++pairs;
                 uint32_t g = c->vals[j];
@@ -322,15 +340,36 @@ static void FN(render_tile)(FN(ctx) *c, int tx, int ty, int64_t *pairs_out)
                 REAL qa = (REAL)0.5 * co[0] * dx * dx, qc = (REAL)0.5 * co[2] * dy * dy, qb = co[1] * dx * dy;
                 REAL power = -(REAL)0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                 REAL mag = R_FABS(qa) + R_FABS(qc) + R_FABS(qb);
-                if (R_FABS(power) <= eps * mag && mag > 0) fragile = 1;   /* sign of power uncertain */
+                /* how far a binary32 evaluation of `power` may sit from this one: rounding of the 2D covariance amplified
+                 * through its determinant (kappa), and the splat's pixel position -- xy ~ W/2 carries an absolute error of a
+                 * few ulps of the image size, which dx = xy - pix inherits in full -- times d power / d xy */
+                const REAL band = eps * c->kappa[g], pband = c->fragile_pos * (R_FABS(co[0] * dx + co[1] * dy) + R_FABS(co[2] * dy + co[1] * dx));
+                if (R_FABS(power) <= band * mag + pband && mag > 0) fragile = 1;   /* sign of power uncertain */
                 if (power > 0) continue;
                 REAL alpha = co[3] * R_EXP(power);
                 if (alpha > (REAL)GSR_ALPHA_MAX) alpha = (REAL)GSR_ALPHA_MAX;
-                if (R_FABS(alpha * 255 - 1) <= eps * (1 + mag)) fragile = 1;
+                if (R_FABS(alpha * 255 - 1) <= band * (1 + mag) + pband) fragile = 1;
+                /* the sort key is the BINARY32 view depth: two list neighbours whose depths sit within a few ulps of each other
+                 * may come in either order in a binary32 evaluation; the blend of two splats does not commute (the colour moves
+                 * by alpha_1 alpha_2 (c_1 - c_2) T, n_contrib by one) when both reach this pixel */
+                {
+                    const float dlo = c->depth_lo[g], dhi = c->depth_hi[g];
+                    const int reaches = alpha * 255 - 1 >= -(band * (1 + mag) + pband);
+                    /* (depths that every evaluation finds bit-identical are ordered by index everywhere: A.7's sort is stable) */
+                    if (reaches && prev_reaches && prev_hi >= dlo && !(prev_lo == prev_hi && dlo == dhi && prev_lo == dlo)) fragile = 1;
+                    /* a neighbour that does not reach the pixel hides nothing: keep the last one that does */
+                    if (reaches) { prev_lo = dlo; prev_hi = dhi > prev_hi || !prev_reaches ? dhi : prev_hi; prev_reaches = 1; }
+                }
                 if (alpha < (REAL)GSR_ALPHA_MIN) continue;
                 REAL test_T = T * (1 - alpha);
-                if (R_FABS(test_T - (REAL)GSR_T_CUTOFF) <= 64 * eps * (REAL)GSR_T_CUTOFF) fragile = 1;
+                /* first-order bound on the relative error of T = prod(1 - alpha_i) in binary32: every factor inherits its
+                 * alpha's uncertainty (the bands above) times alpha / (1 - alpha); 64 eps covers the roundings of the product */
+                /* (an alpha that sits on its 0.99 clamp with room to spare does not move with its inputs) */
+                const REAL rho = band * (1 + mag) + pband;
+                const REAL da = co[3] * R_EXP(power) * (1 - rho) > (REAL)GSR_ALPHA_MAX ? 0 : rho * alpha / (1 - alpha);
+                if (R_FABS(test_T - (REAL)GSR_T_CUTOFF) <= (64 * eps + terr + da) * (REAL)GSR_T_CUTOFF) fragile = 1;
                 if (test_T < (REAL)GSR_T_CUTOFF) break;
+                terr += da;
                 const REAL *col = c->rgb + 3 * g;
                 C[0] += col[0] * alpha * T; C[1] += col[1] * alpha * T; C[2] += col[2] * alpha * T;
                 T = test_T;
@@ -352,9 +391,10 @@ static void FN(render_tile)(FN(ctx) *c, int tx, int ty, int64_t *pairs_out)
                     REAL qa = (REAL)0.5 * co[0] * dx * dx, qc = (REAL)0.5 * co[2] * dy * dy, qb = co[1] * dx * dy;
                     REAL power = -(REAL)0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                     REAL mag = R_FABS(qa) + R_FABS(qc) + R_FABS(qb);
-                    if (power > eps * mag) continue;
+                    const REAL band = eps * c->kappa[g], pband = c->fragile_pos * (R_FABS(co[0] * dx + co[1] * dy) + R_FABS(co[2] * dy + co[1] * dx));
+                    if (power > band * mag + pband) continue;
                     REAL alpha = co[3] * R_EXP(power > 0 ? 0 : power);
-                    if (alpha * 255 - 1 < -eps * (1 + mag)) continue;
+                    if (alpha * 255 - 1 < -(band * (1 + mag) + pband)) continue;
                     c->fragile_g[g] = 1;
                 }
             }
@@ -362,8 +402,57 @@ static void FN(render_tile)(FN(ctx) *c, int tx, int ty, int64_t *pairs_out)
     *pairs_out = pairs;
 }
 
+/* ---- fragile tile membership.  A.5 puts a Gaussian into tile t iff floor((p - r) / 16) <= t < floor((p + r + 15) / 16): where
+ * (p -+ r) sits within the position uncertainty of a multiple of 16 px, a binary32 evaluation may put the Gaussian into one
+ * tile column / row more or less.  The 3-sigma box cuts INSIDE the alpha >= 1/255 ellipse for opacities above ~0.35, so the
+ * pixels of such a tile that the splat reaches are decided by that rounding: they are marked fragile (and the Gaussian with
+ * them) before the blend runs. */
+static void FN(mark_rect_fragile)(FN(ctx) *c)
+{
+    const REAL d = c->fragile_pos, eps = c->fragile_eps;
+    if (!(d > 0)) return;
+    for (int i = 0; i < c->P; ++i) {
+        if (c->radii[i] <= 0) continue;
+        const REAL px = c->xy[2 * i], py = c->xy[2 * i + 1], r = (REAL)c->radii[i];
+        const REAL lo[2] = {px - r, py - r}, hi[2] = {px + r + (GSR_TILE - 1), py + r + (GSR_TILE - 1)};
+        const int G[2] = {c->Gx, c->Gy};
+        int in0[2], in1[2], out0[2], out1[2], any = 0;
+        for (int a = 0; a < 2; ++a) {
+            /* inner rect: surely inside; outer rect: possibly inside */
+            int i0 = (int)((lo[a] + d) / GSR_TILE), o0 = (int)((lo[a] - d) / GSR_TILE);
+            int i1 = (int)((hi[a] - d) / GSR_TILE), o1 = (int)((hi[a] + d) / GSR_TILE);
+            if (lo[a] - d < 0 && lo[a] + d >= 0) o0 = 0;      /* truncation toward zero: (-1, 0] and [0, 1) share tile 0 */
+#define GSO_CLAMP(v, m) ((v) < 0 ? 0 : ((v) > (m) ? (m) : (v)))
+            in0[a] = GSO_CLAMP(i0, G[a]); out0[a] = GSO_CLAMP(o0, G[a]); in1[a] = GSO_CLAMP(i1, G[a]); out1[a] = GSO_CLAMP(o1, G[a]);
+#undef GSO_CLAMP
+            if (in0[a] != out0[a] || in1[a] != out1[a]) any = 1;
+        }
+        if (!any) continue;
+        if (out0[1] < c->ty0) out0[1] = c->ty0;
+        if (out1[1] > c->ty1) out1[1] = c->ty1;
+        const REAL *co = c->conic_op + 4 * i;
+        for (int ty = out0[1]; ty < out1[1]; ++ty)
+            for (int tx = out0[0]; tx < out1[0]; ++tx) {
+                if (tx >= in0[0] && tx < in1[0] && ty >= in0[1] && ty < in1[1]) continue;      /* membership certain */
+                for (int y = ty * GSR_TILE; y < (ty + 1) * GSR_TILE && y < c->H; ++y)
+                    for (int x = tx * GSR_TILE; x < (tx + 1) * GSR_TILE && x < c->W; ++x) {
+                        REAL dx = px - (REAL)x, dy = py - (REAL)y;
+                        REAL qa = (REAL)0.5 * co[0] * dx * dx, qc = (REAL)0.5 * co[2] * dy * dy, qb = co[1] * dx * dy;
+                        REAL power = -(qa + qc) - qb;
+                        REAL mag = R_FABS(qa) + R_FABS(qc) + R_FABS(qb);
+                        const REAL band = eps * c->kappa[i], pband = d * (R_FABS(co[0] * dx + co[1] * dy) + R_FABS(co[2] * dy + co[1] * dx));
+                        if (power > band * mag + pband) continue;
+                        REAL alpha = co[3] * R_EXP(power > 0 ? 0 : power);
+                        if (alpha * 255 - 1 < -(band * (1 + mag) + pband)) continue;
+                        c->fragile_px[(size_t)y * c->W + x] = 1;
+                        c->fragile_g[i] = 1;
+                    }
+            }
+    }
+}
+
 FN(ctx) *FN(forward)(int P, int D, int M, int W, int H, double tanfovx, double tanfovy, double scale_modifier,
-                     int tile_row_begin, int tile_row_end, double fragile_eps, int parallel,
+                     int tile_row_begin, int tile_row_end, double fragile_eps, double fragile_pos, int parallel,
                      const REAL *bg, const REAL *view, const REAL *proj, const REAL *campos,
                      const REAL *means3D, const REAL *shs, const REAL *colors_precomp, const REAL *opacities,
                      const REAL *scales, const REAL *rotations, const REAL *cov3D_precomp)
@@ -375,7 +464,7 @@ FN(ctx) *FN(forward)(int P, int D, int M, int W, int H, double tanfovx, double t
     c->ty1 = (tile_row_end < 0 || tile_row_end > c->Gy) ? c->Gy : tile_row_end;
     c->tanfovx = (REAL)tanfovx; c->tanfovy = (REAL)tanfovy; c->scale_modifier = (REAL)scale_modifier;
     c->focal_x = (REAL)W / (2 * c->tanfovx); c->focal_y = (REAL)H / (2 * c->tanfovy);
-    c->fragile_eps = (REAL)fragile_eps;
+    c->fragile_eps = (REAL)fragile_eps; c->fragile_pos = (REAL)fragile_pos;
     memcpy(c->bg, bg, 3 * sizeof(REAL)); memcpy(c->view, view, 16 * sizeof(REAL));
     memcpy(c->proj, proj, 16 * sizeof(REAL)); memcpy(c->campos, campos, 3 * sizeof(REAL));
     c->has_cov_precomp = cov3D_precomp != NULL; c->has_colors_precomp = colors_precomp != NULL;
@@ -391,6 +480,8 @@ FN(ctx) *FN(forward)(int P, int D, int M, int W, int H, double tanfovx, double t
     c->xy = (REAL *)calloc(2 * Pn, sizeof(REAL)); c->depth = (REAL *)calloc(Pn, sizeof(REAL));
     c->cov3D = (REAL *)calloc(6 * Pn, sizeof(REAL)); c->conic_op = (REAL *)calloc(4 * Pn, sizeof(REAL));
     c->rgb = (REAL *)calloc(3 * Pn, sizeof(REAL)); c->clamped = (uint8_t *)calloc(3 * Pn, 1);
+    c->kappa = (REAL *)calloc(Pn, sizeof(REAL));
+    c->depth_lo = (float *)calloc(Pn, sizeof(float)); c->depth_hi = (float *)calloc(Pn, sizeof(float));
     c->rect = (int32_t *)calloc(4 * Pn, 4); c->tiles_touched = (uint32_t *)calloc(Pn, 4);
     c->ranges = (int64_t *)calloc((size_t)2 * c->Gx * c->Gy, sizeof(int64_t));
     c->color = (REAL *)calloc(3 * N, sizeof(REAL)); c->final_T = (REAL *)calloc(N, sizeof(REAL));
@@ -399,6 +490,7 @@ FN(ctx) *FN(forward)(int P, int D, int M, int W, int H, double tanfovx, double t
 
     FN(preprocess)(c);
     FN(binning)(c);
+    FN(mark_rect_fragile)(c);
     int64_t total_pairs = 0;
     const int Tn_slab = (c->ty1 - c->ty0) * c->Gx;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : total_pairs) if (parallel)

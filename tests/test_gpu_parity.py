@@ -101,11 +101,25 @@ def _strict_pixels(fr64, radii, exact_radii=True):
     return strict
 
 
-def _check_forward(kw, fr64, color, radii, exact_radii=True):
+def _check_forward(kw, fr64, color, radii, exact_radii=True, fr32=None):
+    """Pixels at 1e-5 on the strict (non-fragile) pixels.  `fr32` (the oracle's binary32 instantiation of the same frame) switches
+    to the bound for DEEP lists: with hundreds of composited splats per pixel (cfg3n: 400) a binary32 blend — the reference's own
+    arithmetic restated in binary32 included — sits more than 1e-5 from the exact result on a fraction of a percent of the pixels
+    (every alpha inherits ~1e-4 of relative error from its splat's binary32 screen position at 1080p; measured: 0.41 % of cfg3n's
+    pixels for the binary32 oracle, 5e-5 at most).  There the HIP image must be at least as close to the binary64 result as the
+    binary32 oracle is: no strict pixel beyond 1e-4, and no more pixels beyond 1e-5 than the binary32 oracle has (x1.25 + 1e-4 N)."""
     strict = _strict_pixels(fr64, radii, exact_radii)
     err = np.abs(color.astype(np.float64) - fr64.color).max(0)
     assert strict.mean() > 0.97, f"too many fragile pixels: {1 - strict.mean():.4f}"
-    assert err[strict].max() <= 1e-5, f"pixel error {err[strict].max():.3e} on non-fragile pixels"
+    if fr32 is None:
+        assert err[strict].max() <= 1e-5, f"pixel error {err[strict].max():.3e} on non-fragile pixels"
+    else:
+        ref = np.abs(fr32.color.astype(np.float64) - fr64.color).max(0)
+        n_hip, n_ref = int(((err > 1e-5) & strict).sum()), int(((ref > 1e-5) & strict).sum())
+        print(f"deep lists: {n_hip} strict pixels beyond 1e-5 (binary32 oracle: {n_ref}) of {int(strict.sum())}; max {err[strict].max():.3e} "
+              f"(binary32 oracle: {ref[strict].max():.3e}); mean n_contrib {fr64.n_contrib.mean():.0f}")
+        assert err[strict].max() <= 1e-4, f"pixel error {err[strict].max():.3e} on non-fragile pixels"
+        assert n_hip <= 1.25 * n_ref + 1e-4 * strict.sum(), (n_hip, n_ref)
     if (~strict).any():        # one splat more or less: <= alpha_min * |colour| (+ downstream T change)
         assert err[~strict].max() <= 2e-2, f"fragile-pixel error {err[~strict].max():.3e}"
     return err
@@ -142,7 +156,7 @@ def _check_grads(fr64, want, got, names, masked=False):
 GRAD_NAMES = ("means3D", "means2D", "opacities", "shs", "colors_precomp", "scales", "rotations", "cov3D_precomp")
 
 
-def _forward_backward_strict(kw, fr64, gimg, exact_radii=True, label="", parallel=False):
+def _forward_backward_strict(kw, fr64, gimg, exact_radii=True, label="", parallel=False, fr32=None):
     """The parity check proper: forward at 1e-5 on strict pixels, then the backward of a dL/dcolor that is ZERO on every
     non-strict pixel — identically for the HIP run and the oracle — with EVERY Gaussian held to the strict bound."""
     state = {}
@@ -151,7 +165,7 @@ def _forward_backward_strict(kw, fr64, gimg, exact_radii=True, label="", paralle
         state["strict"] = _strict_pixels(fr64, radii, exact_radii)
         return np.where(state["strict"][None], gimg, 0.0).astype(np.float32)
     color, radii, grads = _run_gpu(kw, masked)
-    _check_forward(kw, fr64, color, radii, exact_radii)
+    _check_forward(kw, fr64, color, radii, exact_radii, fr32=fr32)
     gm = np.where(state["strict"][None], gimg, 0.0).astype(np.float64)
     want = fr64.backward(gm, parallel=parallel)
     names = [n for n in GRAD_NAMES if n in grads]
@@ -352,13 +366,12 @@ def test_empty_and_degenerate_inputs():
 
 def test_image_with_more_than_65536_tiles():
     """4352 x 4112 pixels = 272 x 257 = 69 904 tiles: tile ids need 17 bits, so the per-chunk tile sort takes
-    3 radix passes instead of 2.  Forward + backward against the fp64 oracle, tolerances as everywhere; the
-    fragile-decision band is 5e-5 instead of 2e-6 because the scene's nearest splats are ~3000 px wide and the
-    quadratic form's binary32 rounding grows with the pixel offsets (the oracle's own binary32 instantiation
-    differs from binary64 on 19 pixels at 2e-6, on none at 1e-5)."""
+    3 radix passes instead of 2.  Forward + backward against the fp64 oracle, tolerances as everywhere (the scene's
+    nearest splats are ~3000 px wide: the oracle's fragile-decision bands grow with the image size and with the
+    conditioning of the 2D covariance, oracle/gsr_oracle_impl.h render_tile)."""
     W, H = 4352, 4112
     kw = _fixture_kwargs(dict(P=3000, W=W, H=H, D=1, seed=211))
-    fr64 = oracle.rasterize(dtype=np.float64, fragile_eps=5e-5, parallel=True, **kw)
+    fr64 = oracle.rasterize(dtype=np.float64, parallel=True, **kw)
     assert fr64.Gx * fr64.Gy > 65536
     gimg = S.make_grad_image(W, H, 9).numpy()
     _forward_backward_strict(kw, fr64, gimg, label="69 904 tiles", parallel=True)
@@ -799,14 +812,27 @@ def test_drop_in_l1_loss_and_ssim_match_reference_golden():
 
 def test_cfg3_full_size_vs_oracle():
     """BASELINE.json configs[2] scene at full size (1e6 Gaussians, 1920x1080, SH 3): forward and backward
-    against the fp64 oracle.  This frame exercises everything the progressive pipeline adds: 2 of 3 depth
-    chunks run, 97 % of the reference's 43.8 M instances are never binned (closed tiles + tile culling)."""
+    against the fp64 oracle.  This frame exercises what the progressive pipeline adds: 1 of the planned depth
+    chunks runs, 95 % of the reference's 43.8 M instances are never binned (closed tiles + tile culling)."""
     scene, cam = S.make_config("cfg3")
     kw = raster_kwargs(scene, cam)
     fr64 = oracle.rasterize(dtype=np.float64, parallel=True, **kw)
     gimg = S.make_grad_image(1920, 1080, 3).numpy()
     *_, live = _forward_backward_strict(kw, fr64, gimg, exact_radii=False, label="cfg3", parallel=True)
     assert live > 1000
+
+
+def test_cfg3n_full_size_vs_oracle():
+    """The NON-saturating workload of bench.py's `secondary` line (scene_synth.CONFIGS["cfg3n"]: R/P = 3.55, ~400 composited
+    splats per pixel, 98 % of the visible Gaussians carry a gradient) at full size through the standard API: the variant-B
+    emit + radix path at 2.4 M instances, k_chunk_colors_all and the dense geometry backward against the fp64 oracle."""
+    scene, cam = S.make_config("cfg3n")
+    kw = raster_kwargs(scene, cam)
+    fr64 = oracle.rasterize(dtype=np.float64, parallel=True, **kw)
+    fr32 = oracle.rasterize(dtype=np.float32, parallel=True, **kw)
+    gimg = S.make_grad_image(1920, 1080, 3).numpy()
+    *_, live = _forward_backward_strict(kw, fr64, gimg, exact_radii=False, label="cfg3n", parallel=True, fr32=fr32)
+    assert live > 800_000
 
 
 def test_debug_flag_synchronises_and_matches():

@@ -69,6 +69,42 @@ def test_oracle_f64_matches_torch_autograd(case):
     assert np.all(got["means2D"][:, 2] == 0)
 
 
+def _raw_settings(kw):
+    return {k: kw[k] for k in ("image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+                               "projmatrix", "sh_degree", "campos")}
+
+
+@pytest.mark.parametrize("case", CASES[:2] + CASES[3:], ids=lambda c: f"P{c['P']}_{c['W']}x{c['H']}_D{c['D']}")
+def test_raw_leaves_entry_matches_torch_autograd_through_the_getters(case):
+    """oracle.rasterize_raw = the getters of scene/gaussian_model.py:101-125 (exp / normalize / sigmoid / cat) in binary64 in
+    front of the oracle and their chain rule behind its explicit backward: against torch autograd through the same torch
+    getters and the independent restatement (tests/torch_ref.py), on the raw leaves."""
+    scene, cam = _small_scene(case["P"], case["W"], case["H"], case["D"], case["seed"])
+    kw = raster_kwargs(scene, cam, bg=case.get("bg", (0, 0, 0)))
+    raw = dict(means3D=scene.means3D.numpy(), features=scene.shs.numpy(), opacity_logits=scene.opacity_logits.numpy(),
+               log_scales=scene.log_scales.numpy(), raw_rotations=scene.raw_rotations.numpy())
+    fr = oracle.rasterize_raw(**raw, **_raw_settings(kw))
+    leaves = {k: torch.tensor(v, dtype=torch.float64).requires_grad_(True) for k, v in raw.items()}
+    tk = _to_t64(_raw_settings(kw))
+    color, radii, proxy, _ = render_autograd(
+        means3D=leaves["means3D"], shs=torch.cat((leaves["features"][:, :1], leaves["features"][:, 1:]), dim=1),
+        opacities=torch.sigmoid(leaves["opacity_logits"]), scales=torch.exp(leaves["log_scales"]),
+        rotations=torch.nn.functional.normalize(leaves["raw_rotations"]), **tk)
+    np.testing.assert_array_equal(radii.numpy(), fr.radii)
+    assert np.abs(color.detach().numpy() - fr.color).max() < 1e-12
+    gimg = S.make_grad_image(case["W"], case["H"], case["seed"]).double()
+    (color * gimg).sum().backward()
+    got = fr.backward(gimg.numpy())
+    for leaf, name in (("means3D", "_xyz"), ("features", "_features"), ("opacity_logits", "_opacity"),
+                       ("log_scales", "_scaling"), ("raw_rotations", "_rotation")):
+        want = leaves[leaf].grad.numpy().reshape(got[name].shape)
+        scale = max(np.abs(want).max(), 1e-12)
+        err = np.abs(got[name] - want).max()
+        assert scale > 1e-9 and err <= 1e-9 * scale + 1e-12, f"{name}: {err:.3e} vs scale {scale:.3e}"
+    want2d = proxy.grad.numpy()
+    assert np.abs(got["means2D"][:, :2] - want2d).max() <= 1e-9 * max(np.abs(want2d).max(), 1e-12)
+
+
 def test_oracle_slab_split_sums_to_full():
     """Tile-row slabs (multi-GPU sharding): slab renders tile the image, slab gradients sum."""
     scene, cam = _small_scene(60, 64, 80, 2, 21)
