@@ -83,7 +83,7 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
         "activations_fwd": 64 * P, "activations_bwd": 96 * P,
         "render_fwd": 40 * Re + 20 * N + 4 * Tn,            # K6: id 4 + record 36 per instance; 20 B/px; per tile its walked depth out
         "render_bwd": 76 * Re + 20 * N + 4 * Tn,            # K7: 40 read + 36 written per instance; 20 B/px; its tile from the launch order
-        "tile_order": 8 * Tn,                               # K7's launch order (longest tile first): work in, order out
+        "bwd_units": 12 * Tn,                               # K7 work units (gsr_bwd_units.h): ranges + walked depth in, units out
         "reduce_rows": 36 * Re + 36 * Vb,                   # deterministic reduction (replaces atomic RMW)
         "geom_bwd": 4 * geom_rows + (99 + 12 * K) * Vlive + (40 + 12 * M) * geom_written,        # K8 + K9
         "loss_fwd": 20 * C * N, "loss_bwd": 24 * C * N,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_VERSION 11
+#define GSR_VERSION 12
 #define GSR_SCREEN_GRAD_STRIDE 12   /* floats per Gaussian in `screen_grads`: (dmean2D.x, dmean2D.y,
                                        dconic A, B, C, dopacity, drgb[3], 3 pad) */
 
@@ -84,9 +84,9 @@ typedef struct gsr_frame_plan {
                                                      gsr_forward_render (after GSR_ERR_WORKSPACE) does not sort them again   */
     int32_t chunks_filtered;                      /* bit c: chunk c was put through the live filter (only the Gaussians that can still
                                                      reach an open tile sit at the front of its range, sorted and binned)        */
-    int32_t tile_order_ready;                     /* set by gsr_forward when its zero fill also sorted the slab's tiles for the blend
-                                                     backward's launch order (gsr_backward_render then skips that launch); cleared
-                                                     by gsr_forward_render                                                      */
+    int32_t tile_order_ready;                     /* set by gsr_forward when its zero fill also built the blend backward's list of
+                                                     work units (gsr_backward_render then skips that launch); cleared by
+                                                     gsr_forward_render                                                         */
     int32_t reserved_;
 } gsr_frame_plan;
 
@@ -170,7 +170,7 @@ int gsr_forward(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gau
                 int32_t *radii, gsr_frame_plan *plan_host, void *binning_ws, int64_t binning_capacity, float *out_color,
                 gsr_grads *early_fill, void *stream);
 
-/* Size of the backward-only scratch: one 48-byte gradient row per instance the forward EMITTED
+/* Size of the backward-only scratch: one 48-byte gradient row and one "row written" byte per instance the forward EMITTED
  * (plan_host->instances_emitted, a few per cent of num_rendered; the emission bound of the chunks that ran
  * when the forward went through its last chunk), so it is allocated when the backward runs and freed right
  * after it. */
@@ -185,11 +185,16 @@ int gsr_backward_rows_size(const gsr_frame_desc *desc, const gsr_frame_plan *pla
 int gsr_backward_prepare(const gsr_frame_desc *desc, const gsr_gaussians *g, gsr_frame_plan *plan_host, float *screen_grads,
                          gsr_grads *grads, void *stream);
 
-/* First half of `_C.rasterize_gaussians_backward`: reverse blend of the slab's tiles into rows_ws and the
- * deterministic per-Gaussian reduction -> screen_grads[P, GSR_SCREEN_GRAD_STRIDE]. */
+/* First half of `_C.rasterize_gaussians_backward`: the blend's backward over the slab's tiles into rows_ws and the
+ * deterministic per-Gaussian reduction -> screen_grads[P, GSR_SCREEN_GRAD_STRIDE].  out_color = the image the forward
+ * of this frame wrote ([3,H,W], unchanged since: the backward walks the lists front to back and needs the final pixel). */
 int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const void *geom_ws, void *binning_ws,
-                        const void *image_ws, void *rows_ws, const gsr_frame_plan *plan_host, const float *dL_dcolor,
-                        float *screen_grads, void *stream);
+                        const void *image_ws, void *rows_ws, const gsr_frame_plan *plan_host, const float *out_color,
+                        const float *dL_dcolor, float *screen_grads, void *stream);
+
+/* List entries per work unit of the blend backward (a build constant: binning workspaces hold one 4 KB checkpoint per that
+ * many instances). */
+int gsr_bwd_segment_entries(void);
 
 /* Second half of `_C.rasterize_gaussians_backward`: per-Gaussian backward (2D covariance, projection,
  * SH, 3D covariance) for Gaussians [g_begin, g_end).  Every non-NULL output row in that range is
@@ -246,9 +251,12 @@ typedef struct gsr_debug_views {
     const uint32_t *ranges;        /* [GSR_MAX_CHUNKS, Tn, 2] absolute [start, end) per chunk and tile   */
     const float *final_T;          /* [H*W] (negative sign marks a pixel that hit the cut-off)           */
     const int32_t *n_contrib;      /* [H*W] encoded: (chunk + 1) << 26 | position in that chunk's range  */
-    const uint32_t *tile_work;     /* [Tn] list entries the blend backward walks per tile (deepest contributor, summed over chunks) */
-    const uint32_t *tile_order;    /* [tiles of the slab] valid after gsr_backward_render: its launch order, slab-relative tile
-                                      indices, longest tile first                                        */
+    const uint32_t *tile_walk;     /* [GSR_MAX_CHUNKS, Tn] entries of chunk c's range the blend backward walks on a tile (its deepest
+                                      contributor there); defined where ranges[c][tile] is not empty      */
+    const uint32_t *bwd_units;     /* [*bwd_unit_count, 2] valid after gsr_backward_render (or a gsr_forward with early_fill): the blend
+                                      backward's work units, longest first: (tile | chunk << 24, segment | last-of-its-pair << 31) */
+    const uint32_t *bwd_unit_count; /* [1] */
+    uint64_t bwd_unit_capacity;
 } gsr_debug_views;
 int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws,
                         const void *image_ws, const gsr_frame_plan *plan_host, gsr_debug_views *views);

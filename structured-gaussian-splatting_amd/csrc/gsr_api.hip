@@ -90,6 +90,11 @@ static int validate(const gsr_frame_desc *d)
         set_error("bad frame: P=%d width=%d height=%d", d->P, d->width, d->height);
         return GSR_ERR_INVALID_ARGUMENT;
     }
+    if (((long long)(d->width + GSR_TILE - 1) / GSR_TILE) * ((long long)(d->height + GSR_TILE - 1) / GSR_TILE) >= (1ll << kUnitTileBits)) {
+        set_error("%d x %d pixels: at most 2^%d - 1 tiles per frame (the blend backward's work units pack the tile index)", d->width,
+                  d->height, kUnitTileBits);
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
     if (d->sh_degree < 0 || d->sh_degree > 3) { set_error("sh_degree %d outside 0..3", d->sh_degree); return GSR_ERR_INVALID_ARGUMENT; }
     if (d->sh_coeffs < 0 || d->sh_coeffs > 16) { set_error("sh_coeffs %d outside 0..16", d->sh_coeffs); return GSR_ERR_INVALID_ARGUMENT; }
     if (!(d->tanfovx > 0.f) || !(d->tanfovy > 0.f)) { set_error("tanfov must be positive"); return GSR_ERR_INVALID_ARGUMENT; }
@@ -233,6 +238,28 @@ static int wait_ctrl(const Ctrl *dev, Ctrl *out, hipStream_t s)
     return GSR_OK;
 }
 
+// Instances the backward's scratch must hold: exact when the forward stopped early (the count was read back with the open-tile
+// count); when the LAST chunk ran its count stayed on the device and the bound is what the chunks that ran could have emitted.
+static long long rows_bound(const gsr_frame_plan *plan)
+{
+    long long n = plan->instances_emitted;
+    if (n < 0) {
+        n = 0;
+        for (int c = 0; c < plan->chunks_run && c < GSR_MAX_CHUNKS; ++c) n += plan->chunk_instances_max[c];
+    }
+    return n < 1 ? 1 : n;
+}
+
+// row-valid flags to clear ahead of the blend backward: one byte per instance the chunks that ran can have emitted (never more
+// than the binning workspace holds), rounded up to whole 16-byte words of its padded block
+static size_t valid_bytes(const gsr_frame_plan *plan)
+{
+    long long n = rows_bound(plan);
+    const long long cap = plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered;
+    if (n > cap) n = cap;
+    return ((size_t)(n < 1 ? 1 : n) + 15) & ~(size_t)15;
+}
+
 }  // namespace gsr
 
 using namespace gsr;
@@ -258,7 +285,7 @@ int gsr_binning_size(const gsr_frame_desc *desc, int64_t num_rendered, size_t *b
     int rc = validate(desc);
     if (rc) return rc;
     if (num_rendered < 0 || !binning_bytes) { set_error("bad num_rendered / NULL out"); return GSR_ERR_INVALID_ARGUMENT; }
-    *binning_bytes = carve_binning(nullptr, num_rendered).total;
+    *binning_bytes = carve_binning(nullptr, num_rendered, make_frame(*desc)).total;
     return GSR_OK;
 }
 
@@ -340,7 +367,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
     if (f.P == 0 || plan->num_rendered == 0) {
         // nothing to bin: one blend pass over empty ranges writes the background
         GeomWS gw0 = carve_geom(geom_ws, f.P);
-        BinningWS bw0 = carve_binning(binning_ws, 0);
+        BinningWS bw0 = carve_binning(binning_ws, 0, f);
         if (f.P == 0 || !geom_ws) gw0.ctrl = iw.ctrl_scratch;   // no geometry workspace at all
         if ((rc = launch_binning_init(f, gw0, iw, dbg, s))) return rc;
         if ((rc = launch_render_fwd(f, *cam, 0, true, gw0, bw0, iw, out_color, dbg, s))) return rc;
@@ -353,7 +380,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
     // callers may size it for the first chunk only; a later chunk that does not fit stops the frame with
     // GSR_ERR_WORKSPACE before anything of that chunk is written (re-run this stage with a workspace for R instances).
     const int64_t capacity = plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered;
-    BinningWS bw = carve_binning(binning_ws, capacity);
+    BinningWS bw = carve_binning(binning_ws, capacity, f);
     if (!plan->binning_initialised && (rc = launch_binning_init(f, gw, iw, dbg, s))) return rc;
     plan->binning_initialised = 0;                  // a re-run of this stage must reset the tile ranges / open flags itself
     int sort_result = 0;
@@ -459,11 +486,12 @@ int gsr_forward(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gau
         (long long)plan->chunk_rank_begin[plan->chunks_run] * 4 < (long long)desc->P) {
         const FrameK f = make_frame(*desc);
         const ImageWS iw = carve_image(image_ws, f);
-        bool ordered = false;
+        const BinningWS bw = carve_binning(binning_ws, plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered, f);
+        const BwdUnitArgs ua = bwd_unit_args(f, plan->chunks_run, bw, iw);
         ProfileScope prof("zero_outputs", (hipStream_t)stream);
-        if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream, &iw, &ordered))) return rc;
+        if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream, &ua, bw.row_valid, valid_bytes(plan)))) return rc;
         early_fill->prezeroed = 1;
-        plan->tile_order_ready = ordered ? 1 : 0;        // the fill carried the blend backward's launch order
+        plan->tile_order_ready = 1;                      // the fill carried the blend backward's unit list and cleared its row flags
     }
     return GSR_OK;
 }
@@ -473,15 +501,7 @@ int gsr_backward_rows_size(const gsr_frame_desc *desc, const gsr_frame_plan *pla
     int rc = validate(desc);
     if (rc) return rc;
     if (!plan || !rows_bytes) { set_error("gsr_backward_rows_size: NULL argument"); return GSR_ERR_INVALID_ARGUMENT; }
-    // exact when the forward stopped early (the count was read back with the open-tile count); when the LAST
-    // chunk ran its count stayed on the device and the bound is what the chunks that ran could have emitted
-    long long n = plan->instances_emitted;
-    if (n < 0) {
-        n = 0;
-        for (int c = 0; c < plan->chunks_run && c < GSR_MAX_CHUNKS; ++c) n += plan->chunk_instances_max[c];
-    }
-    if (n < 1) n = 1;
-    *rows_bytes = align_up((size_t)n * kRowFloats * sizeof(float));
+    *rows_bytes = align_up((size_t)rows_bound(plan) * kRowFloats * sizeof(float));
     return GSR_OK;
 }
 
@@ -500,13 +520,15 @@ int gsr_backward_prepare(const gsr_frame_desc *desc, const gsr_gaussians *g, gsr
     return GSR_OK;
 }
 
+int gsr_bwd_segment_entries(void) { return kSeg; }
+
 int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const void *geom_ws, void *binning_ws,
-                        const void *image_ws, void *rows_ws, const gsr_frame_plan *plan, const float *dL_dcolor,
+                        const void *image_ws, void *rows_ws, const gsr_frame_plan *plan, const float *out_color, const float *dL_dcolor,
                         float *screen_grads, void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
-    if (!cam || !cam->bg || !dL_dcolor || !plan || (desc->P > 0 && (!screen_grads || !geom_ws)) || !image_ws ||
+    if (!cam || !cam->bg || !dL_dcolor || !out_color || !plan || (desc->P > 0 && (!screen_grads || !geom_ws)) || !image_ws ||
         (plan->num_rendered > 0 && (!binning_ws || !rows_ws))) {
         set_error("gsr_backward_render: NULL argument");
         return GSR_ERR_INVALID_ARGUMENT;
@@ -517,15 +539,18 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     if (f.P == 0) return GSR_OK;
     GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
     ImageWS iw = carve_image(const_cast<void *>(image_ws), f);
-    BinningWS bw = carve_binning(binning_ws, plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered);
+    BinningWS bw = carve_binning(binning_ws, plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered, f);
     bw.grad_rows = (float *)rows_ws;
-    if (plan->num_rendered > 0 &&
-        (rc = launch_render_bwd(f, *cam, plan->chunks_run, plan->sort_result, gw, bw, iw, dL_dcolor, dbg, s, plan->tile_order_ready != 0)))
-        return rc;
-    // only the depth ranks of chunks that ran can own gradient rows
-    const int n_ranks = (plan->num_rendered > 0 && plan->chunks_run > 0) ? plan->chunk_rank_begin[plan->chunks_run] : 0;
     long long rows_upper = 0;
     for (int c = 0; c < plan->chunks_run && c < GSR_MAX_CHUNKS; ++c) rows_upper += plan->chunk_instances_max[c];
+    if (plan->num_rendered > 0) {
+        if (!plan->tile_order_ready) GSR_HIP_CHECK(hipMemsetAsync(bw.row_valid, 0, valid_bytes(plan), s));
+        if ((rc = launch_render_bwd(f, plan->chunks_run, plan->sort_result, plan->instances_emitted >= 0 ? (long long)plan->instances_emitted : rows_upper,
+                                    gw, bw, iw, out_color, dL_dcolor, dbg, s, plan->tile_order_ready != 0)))
+            return rc;
+    }
+    // only the depth ranks of chunks that ran can own gradient rows
+    const int n_ranks = (plan->num_rendered > 0 && plan->chunks_run > 0) ? plan->chunk_rank_begin[plan->chunks_run] : 0;
     if ((rc = launch_reduce_rows(f, n_ranks, rows_upper, gw, bw, screen_grads, plan->screen_prezeroed, dbg, s))) return rc;
     return GSR_OK;
 }
@@ -671,14 +696,15 @@ int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const v
         v->clamped = gw.clamped;
     }
     if (binning_ws) {
-        BinningWS bw = carve_binning(const_cast<void *>(binning_ws), plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered);
+        BinningWS bw = carve_binning(const_cast<void *>(binning_ws), plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered, f);
         v->sorted_gaussian = bw.sorted_gid;
+        v->bwd_units = reinterpret_cast<const uint32_t *>(bw.units); v->bwd_unit_count = bw.n_units; v->bwd_unit_capacity = bw.unit_capacity;
     }
     if (image_ws) {
         ImageWS iw = carve_image(const_cast<void *>(image_ws), f);
         v->ranges = reinterpret_cast<const uint32_t *>(iw.ranges);
         v->final_T = iw.T_state; v->n_contrib = iw.last_enc;
-        v->tile_work = iw.tile_work; v->tile_order = iw.tile_order;
+        v->tile_walk = iw.tile_walk;
     }
     return GSR_OK;
 }

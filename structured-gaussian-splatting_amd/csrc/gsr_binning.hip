@@ -78,22 +78,27 @@ ImageWS carve_image(void *base, const FrameK &f)
     w.open = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
     w.open_bits = (unsigned long long *)(b + o); o += align_up((size_t)(f.Gy > 0 ? f.Gy : 1) * (size_t)((f.Gx + 63) / 64 + 1) * 8);
     w.ctrl_scratch = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
-    w.tile_work = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
-    w.tile_order = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
+    w.tile_walk = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4 * GSR_MAX_CHUNKS);
+    w.ckpt_start = (float *)(b + o); o += align_up((Tn ? Tn : 1) * (size_t)(GSR_MAX_CHUNKS - 1) * kCkptFloats * sizeof(float));
     w.total = o;
     return w;
 }
 
-BinningWS carve_binning(void *base, int64_t R)
+BinningWS carve_binning(void *base, int64_t R, const FrameK &f)
 {
     BinningWS w;
     size_t o = 0;
     char *b = (char *)base;
-    const size_t Rn = (size_t)(R > 0 ? R : 1);
+    const size_t Rn = (size_t)(R > 0 ? R : 1), Tn = (size_t)f.Gx * f.Gy;
     for (int i = 0; i < 2; ++i) { w.keys[i] = (uint32_t *)(b + o); o += align_up(Rn * 4); }
     for (int i = 0; i < 2; ++i) { w.vals[i] = (uint32_t *)(b + o); o += align_up(Rn * 4); }
     w.inst_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
     w.sorted_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
+    w.row_valid = (uint8_t *)(b + o); o += align_up(Rn);
+    w.ckpt = (float *)(b + o); o += align_up((Rn / kSeg + 2) * (size_t)kCkptFloats * sizeof(float));
+    w.unit_capacity = Rn / kSeg + (size_t)GSR_MAX_CHUNKS * Tn + 1;
+    w.units = (uint2 *)(b + o); o += align_up(w.unit_capacity * sizeof(uint2));
+    w.n_units = (uint32_t *)(b + o); o += align_up(16);
     w.grad_rows = nullptr;                          // backward-only, sized from instances_emitted: gsr_backward_rows_size
     w.total = o;
     return w;

@@ -6,7 +6,7 @@
 // 48 (screen grads) + 44 + 12K + 5 and writes 40 + 12M.  Camera matrices are wave-uniform loads that
 // the compiler scalarises (s_load) — they never cost vector memory bandwidth.
 #include "gsr_internal.h"
-#include "gsr_tile_order.h"
+#include "gsr_bwd_units.h"
 
 namespace gsr {
 
@@ -539,25 +539,22 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
 // ---- one launch that zero-fills up to nine output tensors (the sparse path's "memset"): the segments are laid end to
 // end in a virtual float index space; each thread clears a float4 where the 16 bytes lie inside one segment.
 struct ZeroSegs {
-    float *ptr[10];
-    size_t len[10];      // floats to clear in segment i
-    size_t end[10];     // exclusive end of segment i in the virtual index space (lengths rounded up to 4 floats)
+    float *ptr[11];
+    size_t len[11];      // floats to clear in segment i
+    size_t end[11];     // exclusive end of segment i in the virtual index space (lengths rounded up to 4 floats)
     int n;
 };
 
-// ORDER: block 0 sorts the slab's tiles for the blend backward's launch order instead of filling (gsr_tile_order.h): the
-// frame's forward is complete when this kernel runs, nothing reads the order before the backward, and the sort (one block,
-// ~10 us) disappears behind the other blocks' 45 us of stores: no launch, no stream time of its own.
-struct TileOrderArgs { int n_tiles, tile_base; const uint32_t *work; uint32_t *order; };
-constexpr int kFillOrderPer = 8192 / kGeomBlock;       // tiles per thread of block 0: frames of up to 8192 tiles
-
-template <bool ORDER>
-__global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z, TileOrderArgs o)
+// UNITS: block 0 builds the blend backward's work-unit list instead of filling (gsr_bwd_units.h): the frame's forward is
+// complete when this kernel runs, nothing reads the list before the backward, and the job (one block, ~10 us) disappears
+// behind the other blocks' 45 us of stores: no launch, no stream time of its own.
+template <bool UNITS>
+__global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z, BwdUnitArgs ua)
 {
     unsigned block = blockIdx.x, blocks = gridDim.x;
-    if constexpr (ORDER) {
+    if constexpr (UNITS) {
         if (blockIdx.x == 0) {
-            tile_order_block<kGeomBlock, kFillOrderPer>(o.n_tiles, o.tile_base, o.work, o.order);
+            bwd_units_block<kGeomBlock>(ua);
             return;
         }
         block -= 1; blocks -= 1;
@@ -578,9 +575,8 @@ __global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z, TileOr
 
 // zero-fill of the backward's outputs in ONE launch: screen-space gradients (optional) + every wanted parameter gradient
 int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
-                        const ImageWS *order_iw, bool *ordered)
+                        const BwdUnitArgs *units, uint8_t *row_valid, size_t valid_bytes)
 {
-    if (ordered) *ordered = false;
     const size_t P = (size_t)f.P;
     ZeroSegs z;
     z.n = 0;
@@ -597,19 +593,15 @@ int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, 
     const bool split = raw_split_sh(f, g);
     if (g.shs) add(out.shs, P * 3 * (size_t)(split ? 1 : f.M));
     if (split && f.M > 1) add(out.shs_rest, P * 3 * (size_t)(f.M - 1));
+    if (row_valid && valid_bytes) add(reinterpret_cast<float *>(row_valid), (valid_bytes + 3) / 4);     // (a 256-byte aligned, padded block)
     if (z.n == 0) return GSR_OK;
     const size_t total = z.end[z.n - 1];
     size_t blocks = (total / 4 + kGeomBlock - 1) / kGeomBlock / 4 + 1;
     if (blocks > 8192) blocks = 8192;
-    const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
-    static_assert(kGeomBlock == 256 && kOrderBins % kGeomBlock == 0, "tile_order_block<kGeomBlock, ...> inside the fill");
-    if (order_iw && n_tiles > 0 && n_tiles <= kFillOrderPer * kGeomBlock) {
-        const TileOrderArgs o{n_tiles, f.ty0 * f.Gx, order_iw->tile_work, order_iw->tile_order};
-        hipLaunchKernelGGL(k_zero_segments<true>, dim3((unsigned)blocks + 1), dim3(kGeomBlock), 0, s, z, o);
-        if (ordered) *ordered = true;
-    } else {
-        hipLaunchKernelGGL(k_zero_segments<false>, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z, TileOrderArgs{0, 0, nullptr, nullptr});
-    }
+    if (units && units->n_tiles > 0 && units->chunks_run > 0)
+        hipLaunchKernelGGL(k_zero_segments<true>, dim3((unsigned)blocks + 1), dim3(kGeomBlock), 0, s, z, *units);
+    else
+        hipLaunchKernelGGL(k_zero_segments<false>, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z, BwdUnitArgs{});
     GSR_LAUNCH_CHECK("zero_outputs", false, s);
     return GSR_OK;
 }

@@ -127,6 +127,19 @@ struct GeomWS {                 // O(P): the reference's geomBuffer
     void *radix_temp;
     size_t total;
 };
+// ---- work units of the blend backward (K7).  A tile's list is walked FRONT TO BACK in segments of kSeg entries; the forward
+// leaves the per-pixel state (T, colour) at every segment boundary (a checkpoint), so the segments of one tile are independent
+// work units: (tile, chunk, segment).  kSeg list entries are ~25 us of one wave; a 400-entry tile as ONE unit was 100 us and the
+// launch ended with a third of its time draining (two rounds of 4096 resident waves, tail = the last-started tiles).
+#ifndef GSR_BWD_SEG
+#define GSR_BWD_SEG 128
+#endif
+constexpr int kSeg = GSR_BWD_SEG;
+static_assert(kSeg % kWave == 0, "segments are whole 64-entry batches");
+constexpr int kCkptFloats = 16 * kWave;   // one checkpoint = (T, r, g, b) of the tile's 256 pixels: [quadrant][field][lane], 4 KB
+constexpr int kUnitTileBits = 24;         // BwdUnit.x = tile | chunk << 24; .y = segment | last-segment flag << 31
+constexpr uint32_t kUnitLast = 1u << 31;
+
 struct ImageWS {                // O(N + Tn): the reference's imgBuffer
     float *T_state;             // [N]  running / final transmittance; negative = pixel hit the cut-off
     int32_t *last_enc;          // [N]  (chunk + 1) << 26 | contributor position in that chunk's range
@@ -134,8 +147,9 @@ struct ImageWS {                // O(N + Tn): the reference's imgBuffer
     uint32_t *tile_cnt;         // [Tn] instances per tile of the chunk being binned (gather variant; zero between chunks)
     uint32_t *open;             // [Tn] 1 = tile still has an unsaturated pixel (0 outside the slab)
     unsigned long long *open_bits;   // [Gy][ceil(Gx/64)] the same flags, one bit per tile (rebuilt at chunk boundaries)
-    uint32_t *tile_work;        // [Tn] list entries the backward will walk per tile (written by K6, summed over the chunks)
-    uint32_t *tile_order;       // [Tn] the slab's tiles (relative index), longest first: launch order of K7
+    uint32_t *tile_walk;        // [GSR_MAX_CHUNKS][Tn] entries of chunk c's range the backward walks: the tile's deepest contributor
+                                //      there (written by K6 for every tile that blends in chunk c)
+    float *ckpt_start;          // [GSR_MAX_CHUNKS - 1][Tn][kCkptFloats] the pixels' state when chunk c >= 1 starts on a tile
     Ctrl *ctrl_scratch;         // stand-in control block for frames without a geometry workspace (P == 0)
     size_t total;
 };
@@ -144,7 +158,14 @@ struct BinningWS {              // O(R): the reference's binningBuffer
     uint32_t *vals[2];          // [R] x2 payload = instance slot (absolute index in emission order)
     uint32_t *inst_gid;         // [R] slot -> Gaussian | quadrant mask << 28 (gsr_math.h quadrant_mask_q of the instance's tile)
     uint32_t *sorted_gid;       // [R] sorted position -> the same word
-    float *grad_rows;           // [instances emitted, kRowFloats] per-instance screen-space gradient rows: the caller's
+    uint8_t *row_valid;         // [R] by slot: 1 = the blend backward wrote the instance's gradient row (cleared ahead of it: by the
+                                //      forward's zero fill, or by gsr_backward_render itself)
+    float *ckpt;                // [R / kSeg + 2][kCkptFloats] the pixels' state in front of sorted position p = range start + k kSeg
+                                //      (k >= 1), at slot p / kSeg: ranges are disjoint, so the slots are
+    uint2 *units;               // [R / kSeg + GSR_MAX_CHUNKS Tn + 1] work units of the blend backward, longest first
+    uint32_t *n_units;          // [1]
+    size_t unit_capacity;
+    float *grad_rows;           // [instances emitted, kRowFloats] per-instance screen-space gradient rows, by slot: the caller's
                                 // backward-time allocation (gsr_backward_rows_size), not part of the carved block
     size_t total;
 };
@@ -158,7 +179,7 @@ size_t scan_temp_bytes(int n);
 size_t radix_temp_bytes();
 GeomWS carve_geom(void *base, int P);
 ImageWS carve_image(void *base, const FrameK &f);
-BinningWS carve_binning(void *base, int64_t R);
+BinningWS carve_binning(void *base, int64_t R, const FrameK &f);
 
 // ---- primitives (gsr_sort.hip)
 int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, uint32_t *grand_total, const uint32_t *acc_in,
@@ -197,12 +218,20 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
 int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s, CtrlMirror mirror = CtrlMirror());
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s);
-int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, int sort_result, const GeomWS &gw, BinningWS &bw,
-                      const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s, bool order_ready = false);
-// order_iw: also sort the slab's tiles for the blend backward's launch order inside the fill (frames of up to 8192 tiles;
-// *ordered says whether it did)
+// rows_upper: bound of the instances the chunks that ran emitted (sizes the launch: the unit count lives on the device)
+int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long long rows_upper, const GeomWS &gw, BinningWS &bw,
+                      const ImageWS &iw, const float *out_color, const float *dL_dcolor, bool debug, hipStream_t s, bool units_ready = false);
+// The unit list of the blend backward (gsr_bwd_units.h): what one block needs to build it.
+struct BwdUnitArgs {
+    int n_tiles, tile_base, Tn, chunks_run;       // the slab's tiles are tile_base .. tile_base + n_tiles
+    const uint2 *ranges; const uint32_t *tile_walk;
+    uint2 *units; uint32_t *n_units; uint32_t capacity;
+};
+BwdUnitArgs bwd_unit_args(const FrameK &f, int chunks_run, const BinningWS &bw, const ImageWS &iw);
+// units: also build the blend backward's unit list inside the fill (block 0 of the launch) and clear `valid_bytes` bytes of
+// its row-valid flags
 int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
-                        const ImageWS *order_iw = nullptr, bool *ordered = nullptr);
+                        const BwdUnitArgs *units = nullptr, uint8_t *row_valid = nullptr, size_t valid_bytes = 0);
 int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
                        float *screen_grads, int prezeroed, bool debug, hipStream_t s);
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,

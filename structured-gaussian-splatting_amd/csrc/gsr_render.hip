@@ -8,14 +8,14 @@
 //     and early termination is a wave ballot per quadrant.
 //   * splat records (48 B: xy, conic, opacity, rgb) are gathered 64 at a time, one per lane, staged in
 //     LDS and read back as wave-uniform broadcasts (ds_read_b128, conflict-free by construction).
-//   * backward: each lane first sums a splat's nine partial gradients over its own four pixels in
-//     registers, then ONE DPP row_shr / row_bcast reduction per value crosses the 64 lanes; the wave's
-//     result goes to the splat's private 48-B row (no atomics).  Splats that no pixel of the tile
-//     accepts skip the reduction (wave-uniform ballot).
-//   * workgroup = one wave (64 threads): blockIdx -> tile goes through an XCD-aware bijective remap so
-//     the 8 XCDs each walk a contiguous run of tiles and neighbouring tiles share an L2.
+//   * backward: FRONT TO BACK, in independent work units of kSeg list entries (gsr_bwd_units.h) that start from the
+//     per-pixel state the forward left at the segment boundary.  Each lane first sums a splat's nine partial gradients
+//     over its own four pixels in registers, then a DPP reduction crosses the 64 lanes (two splats per tree); the
+//     wave's result goes to the splat's private 48-B row (no atomics).  Splats that no pixel of the tile
+//     accepts skip the reduction (wave-uniform ballot) and their row is never written (one valid byte per row).
+//   * workgroup = one wave (64 threads); forward: tile = block (consecutive tiles run on different XCDs).
 #include "gsr_internal.h"
-#include "gsr_tile_order.h"
+#include "gsr_bwd_units.h"
 
 namespace gsr {
 
@@ -26,22 +26,6 @@ __device__ __forceinline__ float fast_exp(float x)
 }
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-
-// Bijective XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs (b % 8 names the group);
-// give group x the contiguous run [start(x), start(x) + count(x)) of the n work items.
-__device__ __forceinline__ int xcd_remap(int b, int n)
-{
-    const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
-    return x * q + (x < r ? x : r) + i;
-}
-
-// dst = src + dpp_move(src) with out-of-range / masked-off lanes contributing 0.
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float dpp_add(float v)
-{
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
-    return v + __int_as_float(t);
-}
 
 // Nine independent wave sums in ONE asm block, step-major: v_add_f32_dpp v, v, v <ctrl> computes
 // v = dpp(v) + v (lanes whose DPP source does not exist are disabled and keep v, i.e. add 0).  The same
@@ -90,28 +74,11 @@ __device__ __forceinline__ void wave_sum9_two(float (&a)[9], float (&b)[9])
 }
 #undef GSR_DPP9
 
-// Sum over the 64 lanes; the total lands in lane 63 (other lanes hold partial sums).
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
-{
-    v = dpp_add<0x111, 0xf, 0xf>(v);   // row_shr:1
-    v = dpp_add<0x112, 0xf, 0xf>(v);   // row_shr:2
-    v = dpp_add<0x114, 0xf, 0xf>(v);   // row_shr:4
-    v = dpp_add<0x118, 0xf, 0xf>(v);   // row_shr:8   -> lane 15 of each row = row total
-    v = dpp_add<0x142, 0xf, 0xf>(v);   // row_bcast:15: row r += lane 15 of row r-1 (row 0: no source -> +0)
-    v = dpp_add<0x143, 0xf, 0xf>(v);   // row_bcast:31: rows 2,3 += lane 31          -> lane 63 = total
-    return v;
-}
-
 __device__ __forceinline__ int wave_max_uniform(int v)
 {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
     return __builtin_amdgcn_readfirstlane(v);
-}
-
-__device__ __forceinline__ float bcast_lane63(float v)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 #ifndef GSR_FWD_WAVES
@@ -120,7 +87,6 @@ __device__ __forceinline__ float bcast_lane63(float v)
 #ifndef GSR_BWD_WAVES
 #define GSR_BWD_WAVES 4        // ... and of k_render_bwd
 #endif
-constexpr int kQuads = 4;                                   // 8x8 quadrants of a tile: k = qx + 2 qy
 typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 operand: the lane's two pixels of a pair
 
 // Pixel mapping ("one wave, one tile", QUADRANT-major): lane l owns the pixel (l & 7, l >> 3) of each of the tile's four
@@ -244,7 +210,8 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
                                                       const uint32_t *__restrict__ sorted_gid,
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
                                                       float *__restrict__ out_color, float *__restrict__ T_state,
-                                                      int32_t *__restrict__ last_enc, uint32_t *__restrict__ tile_work)
+                                                      int32_t *__restrict__ last_enc, uint32_t *__restrict__ tile_walk_c,
+                                                      float *__restrict__ ckpt, float *__restrict__ ckpt_start_c)
 {
     __shared__ float4 sh_rec[kWave * 3];
 #ifdef GSR_FWD_TRACE
@@ -286,9 +253,19 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
 
     const int n_total = (int)(rng.y - rng.x);
     const int enc_base = (c + 1) << kLastShift;
+    // The blend backward walks this list front to back in independent segments of kSeg entries (gsr_bwd_units.h): it starts a
+    // segment from the pixels' state (live transmittance, colour so far) in front of the segment's first entry, kept here.
+    auto checkpoint = [&](float *dst) {                 // [quadrant][T, r, g, b][lane]: sixteen coalesced 256-byte stores
+        dst[0 * kWave + lane] = P0.Tl[0]; dst[1 * kWave + lane] = P0.Cr[0]; dst[2 * kWave + lane] = P0.Cg[0]; dst[3 * kWave + lane] = P0.Cb[0];
+        dst[4 * kWave + lane] = P0.Tl[1]; dst[5 * kWave + lane] = P0.Cr[1]; dst[6 * kWave + lane] = P0.Cg[1]; dst[7 * kWave + lane] = P0.Cb[1];
+        dst[8 * kWave + lane] = P1.Tl[0]; dst[9 * kWave + lane] = P1.Cr[0]; dst[10 * kWave + lane] = P1.Cg[0]; dst[11 * kWave + lane] = P1.Cb[0];
+        dst[12 * kWave + lane] = P1.Tl[1]; dst[13 * kWave + lane] = P1.Cr[1]; dst[14 * kWave + lane] = P1.Cg[1]; dst[15 * kWave + lane] = P1.Cb[1];
+    };
+    if (c > 0 && n_total > 0) checkpoint(ckpt_start_c + (size_t)tile * kCkptFloats);
     for (int base = 0; base < n_total; base += kWave) {
         unsigned live = live_quadrants(P0, P1);
         if (live == 0u) break;
+        if (base > 0 && base % kSeg == 0) checkpoint(ckpt + (size_t)((rng.x + (uint32_t)base) / kSeg) * kCkptFloats);
         const int n = min(kWave, n_total - base);
         __syncthreads();
         const unsigned mymask = stage_batch(sh_rec, lane, n, sorted_gid, rng.x + base, records);
@@ -348,7 +325,7 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     const int walked = wave_max_uniform(max(max(depth_here(P0.last0), depth_here(P0.last1)), max(depth_here(P1.last0), depth_here(P1.last1))));
     if (lane == 0) {
         open[tile] = closing ? 0u : (stuck ? 2u : 1u);
-        tile_work[tile] = (c == 0 ? 0u : tile_work[tile]) + (uint32_t)walked;
+        tile_walk_c[tile] = (uint32_t)walked;
     }
 }
 
@@ -361,18 +338,28 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
     const size_t Tn = (size_t)f.Gx * f.Gy;
     hipLaunchKernelGGL(k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, c, last_chunk ? 1 : 0,
                        iw.ranges + (size_t)c * Tn, iw.open, bw.sorted_gid, gw.records, cam.bg, out_color, iw.T_state,
-                       iw.last_enc, iw.tile_work);
+                       iw.last_enc, iw.tile_walk + (size_t)c * Tn, bw.ckpt,
+                       c > 0 ? iw.ckpt_start + (size_t)(c - 1) * Tn * kCkptFloats : nullptr);
     GSR_LAUNCH_CHECK("render_fwd", debug, s);
     return GSR_OK;
 }
 
 // ------------------------------------------------------------------------------------------- K7
-// One launch for the whole frame: a tile's wave walks its chunks last to first, each chunk's range back to
-// front.  A pixel takes part in chunk c up to its own last contributor (all of the range for chunks before
-// the one that holds it, nothing after).
+// One launch for the whole frame, one wave per WORK UNIT (tile, chunk, segment of kSeg list entries), FRONT TO BACK.
 //
-// Per pixel and splat (A.9), written so that a rejected pixel runs the same arithmetic with alpha = 0 and G = 0: T,
-// the colour behind and every partial sum then stay exactly unchanged, and only alpha and G need a select.
+// A.9 walks a pixel's list back to front with the colour behind the current splat as its state.  The same derivative in
+// front-to-back form: with w_j = alpha_j T_j (T_j = transmittance in front of splat j), D_i = sum_{j <= i} w_j <c_j, dL/dpix>
+// (the prefix of the pixel's colour, dotted with the upstream gradient) and Q = <out_color, dL/dpix> (the FINAL pixel,
+// background term T_final bg included),
+//     dL/dalpha_i = T_i <c_i, dL/dpix> - (Q - D_i) / (1 - alpha_i)
+// since (Q - D_i) is what all splats behind i and the background contribute.  The state per pixel is (T, D): T is
+// advanced by the multiplication the forward used (no division by 1 - alpha to recover it), and a walk may start anywhere
+// the forward left (T, colour): a checkpoint every kSeg entries, D = <colour so far, dL/dpix>.  So the segments of a tile
+// are independent units — 21 k units of <= 128 entries instead of 8 160 tiles of ~400 at cfg3n, where the launch used to end
+// with a third of its time draining.
+//
+// Per pixel and splat, written so that a rejected pixel runs the same arithmetic with alpha = 0 and G = 0: T, D and every
+// partial sum then stay exactly unchanged, and only alpha and G need a select.
 //
 // Algebra: with ga = opacity * G (the alpha before its 0.99 clamp; 0 where the pixel rejects the splat) every term of A.9
 // that carries G * dL/dG = G * opacity * dL/dalpha is dL/dalpha * ga, so neither the opacity nor its reciprocal is needed
@@ -383,8 +370,7 @@ struct BwdSplat {            // wave-uniform per-splat values
     float lop, cr, cg, cb, qA2, qB, qC2;       // qA2 = 2 qA, qC2 = 2 qC
 };
 struct BwdPair {             // state of a lane's two pixels in one pair of quadrants (left, right)
-    v2f T, bgterm, dpr, dpg, dpb;      // transmittance behind the current splat, -T_final <bg, dL/dpix>, dL/dpix
-    v2f ar, ag, ab;                    // colour behind the current splat
+    v2f T, D, Q, dpr, dpg, dpb;        // transmittance in front of the current splat, colour prefix . dL/dpix, final pixel . dL/dpix, dL/dpix
     int limit0, limit1;                // contributors of the current chunk each pixel takes part in
 };
 struct BwdAcc { v2f S0, S1, S2, S3, S4, S5, S6, S7, S8; };
@@ -395,160 +381,126 @@ __device__ __forceinline__ float add_halves(v2f v)
     return r;
 }     // the lane's nine partial sums of one splat, per pair element
 
-template <int MODE>          // 3: both quadrants of the pair (packed), 1: the left one only, 2: the right one only
 __device__ __forceinline__ bool bwd_pair(const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
 {
-    if constexpr (MODE == 3) {
-        const float araw0 = __builtin_amdgcn_exp2f(lp[0]), araw1 = __builtin_amdgcn_exp2f(lp[1]);      // = opacity * G
-        const float alpha0 = fminf((float)GSR_ALPHA_MAX, araw0), alpha1 = fminf((float)GSR_ALPHA_MAX, araw1);
-        const bool valid0 = (pos < P.limit0) && !(lp[0] > sp.lop) && !(alpha0 < (float)GSR_ALPHA_MIN);      // power > 0 <=> lp > lop
-        const bool valid1 = (pos < P.limit1) && !(lp[1] > sp.lop) && !(alpha1 < (float)GSR_ALPHA_MIN);
-        const v2f ae = {valid0 ? alpha0 : 0.f, valid1 ? alpha1 : 0.f};
-        const v2f ga = {valid0 ? araw0 : 0.f, valid1 ? araw1 : 0.f};
-        const v2f one_m = 1.f - ae;
-        const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
-        const v2f Tn_ = P.T * inv1ma;                         // T before this splat
-        const v2f w = ae * Tn_;                               // d colour / d rgb
-        // colour behind this splat (A.9's accum_rec), updated as soon as the splat is processed: B <- alpha c + (1 - alpha) B
-        const v2f dr = sp.cr - P.ar, dg = sp.cg - P.ag, db = sp.cb - P.ab;
-        v2f dL_dalpha = dr * P.dpr + dg * P.dpg + db * P.dpb;
-        P.ar += ae * dr; P.ag += ae * dg; P.ab += ae * db;
-        dL_dalpha = dL_dalpha * Tn_ + P.bgterm * inv1ma;
-        const v2f tA = dL_dalpha * ga;
-        const v2f tx = tA * dx, ty = tA * dy;
-        A.S0 += sp.qA2 * tx + sp.qB * ty;
-        A.S1 += sp.qC2 * ty + sp.qB * tx;
-        A.S2 += tx * dx;
-        A.S3 += tx * dy;
-        A.S4 += ty * dy;
-        A.S5 += tA;
-        A.S6 += w * P.dpr; A.S7 += w * P.dpg; A.S8 += w * P.dpb;
-        P.T = Tn_;
-        return valid0 || valid1;
-    } else {
-        constexpr int e = MODE - 1;
-        const float araw = __builtin_amdgcn_exp2f(lp[e]);
-        const float alpha = fminf((float)GSR_ALPHA_MAX, araw);
-        const bool valid = (pos < (e ? P.limit1 : P.limit0)) && !(lp[e] > sp.lop) && !(alpha < (float)GSR_ALPHA_MIN);
-        const float ae = valid ? alpha : 0.f;
-        const float ga = valid ? araw : 0.f;
-        const float inv1ma = fast_rcp(1.f - ae);
-        const float Tn_ = P.T[e] * inv1ma;
-        const float w = ae * Tn_;
-        const float dr = sp.cr - P.ar[e], dg = sp.cg - P.ag[e], db = sp.cb - P.ab[e];
-        float dL_dalpha = dr * P.dpr[e] + dg * P.dpg[e] + db * P.dpb[e];
-        P.ar[e] += ae * dr; P.ag[e] += ae * dg; P.ab[e] += ae * db;
-        dL_dalpha = dL_dalpha * Tn_ + P.bgterm[e] * inv1ma;
-        const float tA = dL_dalpha * ga;
-        const float tx = tA * dx[e], ty = tA * dy;
-        A.S0[e] += sp.qA2 * tx + sp.qB * ty;
-        A.S1[e] += sp.qC2 * ty + sp.qB * tx;
-        A.S2[e] += tx * dx[e];
-        A.S3[e] += tx * dy;
-        A.S4[e] += ty * dy;
-        A.S5[e] += tA;
-        A.S6[e] += w * P.dpr[e]; A.S7[e] += w * P.dpg[e]; A.S8[e] += w * P.dpb[e];
-        P.T[e] = Tn_;
-        return valid;
-    }
+    const float araw0 = __builtin_amdgcn_exp2f(lp[0]), araw1 = __builtin_amdgcn_exp2f(lp[1]);      // = opacity * G
+    const float alpha0 = fminf((float)GSR_ALPHA_MAX, araw0), alpha1 = fminf((float)GSR_ALPHA_MAX, araw1);
+    const bool valid0 = (pos < P.limit0) && !(lp[0] > sp.lop) && !(alpha0 < (float)GSR_ALPHA_MIN);      // power > 0 <=> lp > lop
+    const bool valid1 = (pos < P.limit1) && !(lp[1] > sp.lop) && !(alpha1 < (float)GSR_ALPHA_MIN);
+    const v2f ae = {valid0 ? alpha0 : 0.f, valid1 ? alpha1 : 0.f};
+    const v2f ga = {valid0 ? araw0 : 0.f, valid1 ? araw1 : 0.f};
+    const v2f one_m = 1.f - ae;
+    const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
+    const v2f cdp = sp.cr * P.dpr + sp.cg * P.dpg + sp.cb * P.dpb;      // <c_i, dL/dpix>
+    const v2f w = ae * P.T;                                              // d colour / d rgb
+    P.D += w * cdp;                                                      // prefix including this splat
+    const v2f dL_dalpha = P.T * cdp - (P.Q - P.D) * inv1ma;
+    P.T = P.T * one_m;                                                   // exactly the forward's update
+    const v2f tA = dL_dalpha * ga;
+    const v2f tx = tA * dx, ty = tA * dy;
+    A.S0 += sp.qA2 * tx + sp.qB * ty;
+    A.S1 += sp.qC2 * ty + sp.qB * tx;
+    A.S2 += tx * dx;
+    A.S3 += tx * dy;
+    A.S4 += ty * dy;
+    A.S5 += tA;
+    A.S6 += w * P.dpr; A.S7 += w * P.dpg; A.S8 += w * P.dpb;
+    return valid0 || valid1;
 }
 
-// A pair runs packed whenever either of its quadrants is wanted: a clear mask bit means that no pixel of that quadrant
-// accepts the splat, so its lanes of the packed arithmetic find `valid` false on their own.  (Scalar variants for a
-// single wanted quadrant, GSR_BWD_SINGLE, cost more in register moves and occupancy than they save: DESIGN section 7.)
-__device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
+// The unit list (gsr_bwd_units.h) in its own launch: only when the forward's zero fill did not carry it (k_zero_segments<true>,
+// gsr_geom.hip).
+__global__ __launch_bounds__(1024) void k_bwd_units(BwdUnitArgs a) { bwd_units_block<1024>(a); }
+
+BwdUnitArgs bwd_unit_args(const FrameK &f, int chunks_run, const BinningWS &bw, const ImageWS &iw)
 {
-#ifdef GSR_BWD_SINGLE
-    if (mp == 1u) return bwd_pair<1>(sp, lp, dx, dy, pos, P, A);
-    if (mp == 2u) return bwd_pair<2>(sp, lp, dx, dy, pos, P, A);
-#endif
-    return bwd_pair<3>(sp, lp, dx, dy, pos, P, A);
+    BwdUnitArgs a;
+    a.n_tiles = (f.ty1 - f.ty0) * f.Gx; a.tile_base = f.ty0 * f.Gx; a.Tn = f.Gx * f.Gy; a.chunks_run = chunks_run;
+    a.ranges = iw.ranges; a.tile_walk = iw.tile_walk;
+    a.units = bw.units; a.n_units = bw.n_units;
+    a.capacity = (uint32_t)(bw.unit_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : bw.unit_capacity);
+    return a;
 }
 
-// Launch order of K7 (gsr_tile_order.h): the slab's tiles by the work the forward measured, longest first.  Its own launch
-// only when the forward's zero fill did not carry it (k_zero_segments<true>, gsr_geom.hip) or the frame has more than 8192 tiles.
-template <int kOrderPer>
-__global__ __launch_bounds__(kOrderThreads) void k_tile_order(int n_tiles, int tile_base, const uint32_t *__restrict__ tile_work,
-                                                              uint32_t *__restrict__ tile_order)
-{
-    tile_order_block<kOrderThreads, kOrderPer>(n_tiles, tile_base, tile_work, tile_order);
-}
-
-__global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, int n_tiles, int chunks_run, const uint2 *__restrict__ ranges,
-                                                      const uint32_t *__restrict__ sorted_gid,
-                                                      const uint32_t *__restrict__ sorted_slot,
-                                                      const float4 *__restrict__ records, const float *__restrict__ bg,
+__global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, const uint2 *__restrict__ ranges,
+                                                      const uint32_t *__restrict__ tile_walk,
+                                                      const uint32_t *__restrict__ sorted_gid, const uint32_t *__restrict__ sorted_slot,
+                                                      const float4 *__restrict__ records, const float *__restrict__ out_color,
                                                       const float *__restrict__ T_state, const int32_t *__restrict__ last_enc,
-                                                      const float *__restrict__ dL_dpix, float4 *__restrict__ grad_rows,
-                                                      const uint32_t *__restrict__ tile_order)
+                                                      const float *__restrict__ dL_dpix, const float *__restrict__ ckpt,
+                                                      const float *__restrict__ ckpt_start, float4 *__restrict__ grad_rows,
+                                                      uint8_t *__restrict__ row_valid, const uint2 *__restrict__ units,
+                                                      const uint32_t *__restrict__ n_units_ptr)
 {
     __shared__ float4 sh_rec[kWave * 3];
 #ifdef GSR_BWD_TRACE
     TraceEnd trace_end{(unsigned long long)wall_clock64(), (int)blockIdx.x};
 #endif
-    const int t = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, n_tiles);
-    const int tx = t % f.Gx, ty = f.ty0 + t / f.Gx;
-    const int tile = ty * f.Gx + tx;
+    const uint32_t n_units = *n_units_ptr;
     const size_t Tn = (size_t)f.Gx * f.Gy;
     const int lane = threadIdx.x;
-    const int px0 = tx * GSR_TILE + lane_px(lane), py0 = ty * GSR_TILE + lane_py(lane);
-    const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 8.f;
     const size_t N = (size_t)f.W * f.H;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-
-    // Per-pixel state in PAIRS (the left and right quadrant of a tile half) as 2-vectors: when both quadrants are wanted
-    // the arithmetic compiles to packed fp32 instructions, two pixels per VALU issue.
-    BwdPair P0, P1;
-    int c_last[kQuads], n_last[kQuads];
-    auto load_px = [&](int k, float &Tk, float &bt, float &r_, float &g_, float &b_) {
-        const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
-        const bool inside = px < f.W && py < f.H;
-        const size_t pix = inside ? (size_t)py * f.W + px : 0;
-        Tk = inside ? fabsf(T_state[pix]) : 0.f;
-        const int enc = inside ? last_enc[pix] : 0;
-        c_last[k] = (enc >> kLastShift) - 1;                              // -1: no contributor at all
-        n_last[k] = enc & ((1 << kLastShift) - 1);
-        r_ = inside ? dL_dpix[pix] : 0.f; g_ = inside ? dL_dpix[N + pix] : 0.f; b_ = inside ? dL_dpix[2 * N + pix] : 0.f;
-        bt = -Tk * (bg0 * r_ + bg1 * g_ + bg2 * b_);                       // -T_final * <bg, dL/dpix>
-    };
-    {
-        float Ta, ba, ra, ga, bla, Tb, bb, rb, gb, blb;
-        load_px(0, Ta, ba, ra, ga, bla); load_px(1, Tb, bb, rb, gb, blb);
-        P0.T = v2f{Ta, Tb}; P0.bgterm = v2f{ba, bb}; P0.dpr = v2f{ra, rb}; P0.dpg = v2f{ga, gb}; P0.dpb = v2f{bla, blb};
-        load_px(2, Ta, ba, ra, ga, bla); load_px(3, Tb, bb, rb, gb, blb);
-        P1.T = v2f{Ta, Tb}; P1.bgterm = v2f{ba, bb}; P1.dpr = v2f{ra, rb}; P1.dpg = v2f{ga, gb}; P1.dpb = v2f{bla, blb};
-    }
-    P0.ar = P0.ag = P0.ab = P1.ar = P1.ag = P1.ab = v2f{0.f, 0.f};
     const float half_w = 0.5f * (float)f.W, half_h = 0.5f * (float)f.H;
-
-    for (int c = chunks_run - 1; c >= 0; --c) {
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const uint2 unit = units[u];
+        const int tile = (int)(unit.x & ((1u << kUnitTileBits) - 1u)), c = (int)(unit.x >> kUnitTileBits);
+        const int sgm = (int)(unit.y & ~kUnitLast);
+        const int ty = tile / f.Gx, tx = tile - ty * f.Gx;
+        const int px0 = tx * GSR_TILE + lane_px(lane), py0 = ty * GSR_TILE + lane_py(lane);
+        const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 8.f;
         const uint2 rng = ranges[(size_t)c * Tn + tile];
         const int n_total = (int)(rng.y - rng.x);
-        if (n_total == 0) continue;
-        // per pixel: contributors of this chunk it takes part in; per quadrant: the wave's maximum
-        auto lim = [&](int k) { return c < c_last[k] ? n_total : (c == c_last[k] ? n_last[k] : 0); };
-        P0.limit0 = lim(0); P0.limit1 = lim(1); P1.limit0 = lim(2); P1.limit1 = lim(3);
-        const int qmax0 = wave_max_uniform(P0.limit0), qmax1 = wave_max_uniform(P0.limit1), qmax2 = wave_max_uniform(P1.limit0),
-                  qmax3 = wave_max_uniform(P1.limit1);
+        const int seg_begin = sgm * kSeg, seg_end = min(n_total, seg_begin + kSeg);
+        const int walk_end = min(seg_end, (int)tile_walk[(size_t)c * Tn + tile]);       // nothing behind it was composited in this chunk
+
+        // Per-pixel state in PAIRS (the left and right quadrant of a tile half) as 2-vectors: the arithmetic compiles to packed
+        // fp32 instructions, two pixels per VALU issue.  A pixel takes part up to its own last contributor (all of the range for
+        // chunks before the one that holds it, nothing after).
+        BwdPair P0, P1;
+        const float *chk = (sgm > 0) ? ckpt + (size_t)((rng.x + (uint32_t)seg_begin) / kSeg) * kCkptFloats
+                                     : (c > 0 ? ckpt_start + ((size_t)(c - 1) * Tn + tile) * kCkptFloats : nullptr);
+        auto load_px = [&](int k, float &Tk, float &Dk, float &Qk, float &r_, float &g_, float &b_, int &limit) {
+            const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
+            const bool inside = px < f.W && py < f.H;
+            const size_t pix = inside ? (size_t)py * f.W + px : 0;
+            const int enc = inside ? last_enc[pix] : 0;
+            const int c_last = (enc >> kLastShift) - 1;                              // -1: no contributor at all
+            limit = c < c_last ? n_total : (c == c_last ? (enc & ((1 << kLastShift) - 1)) : 0);
+            r_ = inside ? dL_dpix[pix] : 0.f; g_ = inside ? dL_dpix[N + pix] : 0.f; b_ = inside ? dL_dpix[2 * N + pix] : 0.f;
+            Qk = inside ? out_color[pix] * r_ + out_color[N + pix] * g_ + out_color[2 * N + pix] * b_ : 0.f;
+            Tk = 1.f; Dk = 0.f;
+            if (chk) {
+                const float *q = chk + 4 * k * kWave + lane;
+                Tk = q[0];
+                Dk = q[kWave] * r_ + q[2 * kWave] * g_ + q[3 * kWave] * b_;
+            }
+        };
+        {
+            float Ta, Da, Qa, ra, ga, bla, Tb, Db, Qb, rb, gb, blb;
+            load_px(0, Ta, Da, Qa, ra, ga, bla, P0.limit0); load_px(1, Tb, Db, Qb, rb, gb, blb, P0.limit1);
+            P0.T = v2f{Ta, Tb}; P0.D = v2f{Da, Db}; P0.Q = v2f{Qa, Qb}; P0.dpr = v2f{ra, rb}; P0.dpg = v2f{ga, gb}; P0.dpb = v2f{bla, blb};
+            load_px(2, Ta, Da, Qa, ra, ga, bla, P1.limit0); load_px(3, Tb, Db, Qb, rb, gb, blb, P1.limit1);
+            P1.T = v2f{Ta, Tb}; P1.D = v2f{Da, Db}; P1.Q = v2f{Qa, Qb}; P1.dpr = v2f{ra, rb}; P1.dpg = v2f{ga, gb}; P1.dpb = v2f{bla, blb};
+        }
+        // per quadrant: the wave's last participating contributor
+        const int qmax0 = min(walk_end, wave_max_uniform(P0.limit0)), qmax1 = min(walk_end, wave_max_uniform(P0.limit1)),
+                  qmax2 = min(walk_end, wave_max_uniform(P1.limit0)), qmax3 = min(walk_end, wave_max_uniform(P1.limit1));
         const int max_contrib = max(max(qmax0, qmax1), max(qmax2, qmax3));
 
-        const int n_batches = (n_total + kWave - 1) / kWave;
-        for (int bi = n_batches - 1; bi >= 0; --bi) {
-            const int base = bi * kWave;
-            const int n = min(kWave, n_total - base);
-            uint32_t slot = 0;
-            if (lane < n) slot = sorted_slot[rng.x + base + lane];
-            unsigned long long written = 0ull;                 // wave-uniform: bit j = splat j's row stored
-            if (base < max_contrib) {
+        for (int base = seg_begin; base < seg_end; base += kWave) {
+            if (base >= max_contrib) break;                    // nothing behind it was composited: those rows are never written
+            const int n = min(kWave, seg_end - base);
+            const uint32_t slot = lane < n ? sorted_slot[rng.x + base + lane] : 0u;      // the instance's gradient row
+            {
                 __syncthreads();
                 unsigned mymask = stage_batch(sh_rec, lane, n, sorted_gid, rng.x + base, records);
                 __syncthreads();
                 // quadrants whose pixels all stopped before a splat take no part in it (contributor index = pos + 1)
                 const int mypos = base + lane;
                 mymask &= (mypos < qmax0 ? 1u : 0u) | (mypos < qmax1 ? 2u : 0u) | (mypos < qmax2 ? 4u : 0u) | (mypos < qmax3 ? 8u : 0u);
-                unsigned long long act = __ballot(mymask != 0u);       // splats with work, walked back to front
+                unsigned long long act = __ballot(mymask != 0u);       // splats with work, walked front to back
                 // One splat's pass over the tile: the lane's nine partial sums (both pairs, both pair elements added up).
-                // Returns false when no pixel of the tile accepted the splat (its row stays 0).
+                // Returns false when no pixel of the tile accepted the splat (its row is not written).
                 auto splat_pass = [&](int j, float (&s)[9], float &lop) -> bool {
                     const int pos = base + j;
                     const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mymask, j);
@@ -562,13 +514,15 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
                     BwdAcc A;
                     A.S0 = A.S1 = A.S2 = A.S3 = A.S4 = A.S5 = A.S6 = A.S7 = A.S8 = v2f{0.f, 0.f};
                     bool any_valid = false;
+                    // a pair runs packed whenever either of its quadrants is wanted: a clear mask bit means that no pixel of that
+                    // quadrant accepts the splat, so its lanes of the packed arithmetic find `valid` false on their own
                     if (m & 3u) {
                         const float dy = a.y - fy0;
-                        any_valid = bwd_pair_dispatch(m & 3u, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P0, A);
+                        any_valid = bwd_pair(sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P0, A);
                     }
                     if (m & 12u) {
                         const float dy = a.y - fy1;
-                        const bool v = bwd_pair_dispatch(m >> 2, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P1, A);
+                        const bool v = bwd_pair(sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P1, A);
                         any_valid = any_valid || v;
                     }
                     if (__ballot(any_valid) == 0ull) return false;
@@ -582,6 +536,7 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
                 auto store_row = [&](const float (&s)[9], float lop, uint32_t slot_j) {
                     const float inv_op = __builtin_amdgcn_exp2f(-lop);                  // 1 / opacity
                     float4 *row = grad_rows + 3 * (size_t)slot_j;
+                    row_valid[slot_j] = 1;                                              // (cleared ahead of the launch; rows nobody writes are never read)
                     // -(tx cA + ty cB) = ln2 (2 qA tx + qB ty), likewise for y; gA, gB, gC carry the -1/2 of A.9
                     row[0] = make_float4(s[0] * (0.69314718f * half_w), s[1] * (0.69314718f * half_h), s[2] * -0.5f, s[3] * -0.5f);
                     row[1] = make_float4(s[4] * -0.5f, s[5] * inv_op, s[6], s[7]);
@@ -596,8 +551,8 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
                     int j1 = 0;
                     bool have1 = false;
                     while (act != 0ull && !have1) {
-                        j1 = 63 - __builtin_clzll(act);
-                        act &= ~(1ull << j1);
+                        j1 = __ffsll((long long)act) - 1;
+                        act &= act - 1ull;
                         have1 = splat_pass(j1, s1, lop1);
                     }
                     if (!have1) break;
@@ -605,52 +560,45 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, i
                     int j2 = 0;
                     bool have2 = false;
                     while (act != 0ull && !have2) {
-                        j2 = 63 - __builtin_clzll(act);
-                        act &= ~(1ull << j2);
+                        j2 = __ffsll((long long)act) - 1;
+                        act &= act - 1ull;
                         have2 = splat_pass(j2, s2, lop2);
                     }
                     if (have2) {
-                        written |= (1ull << j1) | (1ull << j2);
                         wave_sum9_two(s1, s2);                                   // s1: splat j1 in lane 31, splat j2 in lane 63
                         const uint32_t slot1 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j1);
                         const uint32_t slot2 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j2);
                         if ((lane & 31) == 31) store_row(s1, lane < 32 ? lop1 : lop2, lane < 32 ? slot1 : slot2);
                     } else {
-                        written |= 1ull << j1;
                         wave_sum9_to_lane63(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7], s1[8]);
                         const uint32_t slot1 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j1);
                         if (lane == kWave - 1) store_row(s1, lop1, slot1);
                     }
                 }
             }
-            // rows of splats that were never reduced (past every pixel's last contributor, or accepted by nobody)
-            if (lane < n && !((written >> lane) & 1ull)) {
-                float4 *row = grad_rows + 3 * (size_t)slot;
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                row[0] = z; row[1] = z; row[2] = z;
-            }
         }
     }
 }
 
-int launch_render_bwd(const FrameK &f, const gsr_camera &cam, int chunks_run, int sort_result, const GeomWS &gw, BinningWS &bw,
-                      const ImageWS &iw, const float *dL_dcolor, bool debug, hipStream_t s, bool order_ready)
+int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long long rows_upper, const GeomWS &gw, BinningWS &bw,
+                      const ImageWS &iw, const float *out_color, const float *dL_dcolor, bool debug, hipStream_t s, bool units_ready)
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0 || chunks_run <= 0) return GSR_OK;
-    static const bool in_tile_order = [] { const char *e = getenv("GSR_BWD_TILE_ORDER"); return e && atoi(e) != 0; }();
-    if (!in_tile_order && !order_ready) {
-        ProfileScope prof("tile_order", s);
-        if (n_tiles <= 8 * kOrderThreads)
-            hipLaunchKernelGGL(k_tile_order<8>, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);
-        else
-            hipLaunchKernelGGL(k_tile_order<32>, dim3(1), dim3(kOrderThreads), 0, s, n_tiles, f.ty0 * f.Gx, iw.tile_work, iw.tile_order);
-        GSR_LAUNCH_CHECK("tile_order", debug, s);
+    if (!units_ready) {
+        ProfileScope prof("bwd_units", s);
+        hipLaunchKernelGGL(k_bwd_units, dim3(1), dim3(1024), 0, s, bwd_unit_args(f, chunks_run, bw, iw));
+        GSR_LAUNCH_CHECK("bwd_units", debug, s);
     }
+    // one block per unit while they fit the grid; the count is the device's (gsr_bwd_units.h), the bound the host's: every
+    // (tile, chunk) pair has at most n / kSeg + 1 units
+    long long grid = rows_upper / kSeg + (long long)n_tiles * chunks_run + 1;
+    if (grid > (long long)bw.unit_capacity) grid = (long long)bw.unit_capacity;
+    if (grid > (1 << 16)) grid = 1 << 16;
     ProfileScope prof("render_bwd", s);
-    hipLaunchKernelGGL(k_render_bwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, chunks_run, iw.ranges, bw.sorted_gid,
-                       bw.vals[sort_result], gw.records, cam.bg, iw.T_state, iw.last_enc, dL_dcolor,
-                       reinterpret_cast<float4 *>(bw.grad_rows), in_tile_order ? nullptr : iw.tile_order);
+    hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)grid), dim3(kWave), 0, s, f, iw.ranges, iw.tile_walk, bw.sorted_gid, bw.vals[sort_result], gw.records, out_color,
+                       iw.T_state, iw.last_enc, dL_dcolor, bw.ckpt, iw.ckpt_start, reinterpret_cast<float4 *>(bw.grad_rows), bw.row_valid,
+                       bw.units, bw.n_units);
     GSR_LAUNCH_CHECK("render_bwd", debug, s);
     return GSR_OK;
 }
@@ -665,6 +613,7 @@ template <int kRedGroup>
 __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const uint32_t *__restrict__ order,
                                                            const uint32_t *__restrict__ cnt_open,
                                                            const uint32_t *__restrict__ row_begin,
+                                                           const uint8_t *__restrict__ row_valid,
                                                            const float4 *__restrict__ grad_rows, float4 *__restrict__ screen,
                                                            int write_empty)
 {
@@ -677,7 +626,8 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const ui
     if (cnt) {
         const uint32_t begin = row_begin[r];
         for (uint32_t sl = begin + sub; sl < begin + cnt; sl += kRedGroup) {
-            const float4 r0 = grad_rows[3 * (size_t)sl], r1 = grad_rows[3 * (size_t)sl + 1];
+            if (!row_valid[sl]) continue;               // nobody walked that far into the tile's list, or no pixel accepted the splat:
+            const float4 r0 = grad_rows[3 * (size_t)sl], r1 = grad_rows[3 * (size_t)sl + 1];      // the row was never written
             const float r2 = grad_rows[3 * (size_t)sl + 2].x;
             a0.x += r0.x; a0.y += r0.y; a0.z += r0.z; a0.w += r0.w;
             a1.x += r1.x; a1.y += r1.y; a1.z += r1.z; a1.w += r1.w;
@@ -713,10 +663,10 @@ int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const
         const dim3 grid((unsigned)((threads + kRedBlock - 1) / kRedBlock));
         if (wide)
             hipLaunchKernelGGL(k_reduce_rows<64>, grid, dim3(kRedBlock), 0, s, n_ranks, gw.order, gw.cnt_open, gw.row_begin,
-                               reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
+                               bw.row_valid, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
         else
             hipLaunchKernelGGL(k_reduce_rows<8>, grid, dim3(kRedBlock), 0, s, n_ranks, gw.order, gw.cnt_open, gw.row_begin,
-                               reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
+                               bw.row_valid, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
     }
     GSR_LAUNCH_CHECK("reduce_rows", debug, s);
     return GSR_OK;

@@ -63,10 +63,12 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(-(-n // step) * step, dtype=torch.uint8, device=device)
 
 
-def _binning_bytes(n: int) -> int:
-    """gsr_binning_size(desc, n) without the call: six u32 arrays of max(n, 1) entries, each padded to 256 bytes
-    (csrc/gsr_binning.hip carve_binning; tests/test_abi.py holds the two together)."""
-    return 6 * ((4 * max(int(n), 1) + 255) // 256 * 256)
+def _binning_bytes(n: int, tiles: int) -> int:
+    """gsr_binning_size(desc, n) without the call (csrc/gsr_binning.hip carve_binning; tests/test_abi.py holds the two together):
+    six u32 arrays and one byte array of max(n, 1) entries, one 4 KB checkpoint per `seg` instances (+ 2), the blend backward's
+    unit list (n / seg + 8 tiles + 1 units of 8 bytes) and its count, each block padded to 256 bytes."""
+    n, seg, up = max(int(n), 1), N.bwd_segment_entries(), lambda b: (b + 255) // 256 * 256
+    return 6 * up(4 * n) + up(n) + up((n // seg + 2) * 4096) + up((n // seg + N.MAX_CHUNKS * int(tiles) + 1) * 8) + 256
 
 
 _binning_guess = {}        # (P, W, H, slab, device) -> instances the binning workspace of that frame shape last had to hold
@@ -74,7 +76,7 @@ _binning_guess = {}        # (P, W, H, slab, device) -> instances the binning wo
 
 class _Frame:
     """Native handles of one forward pass, kept alive by autograd's ctx for the backward."""
-    __slots__ = ("desc", "cam", "keep", "plan", "geom_ws", "binning_ws", "image_ws", "radii", "gauss", "M", "device", "raw", "pre")
+    __slots__ = ("desc", "cam", "keep", "plan", "geom_ws", "binning_ws", "image_ws", "radii", "color", "gauss", "M", "device", "raw", "pre")
 
     @property
     def R(self):
@@ -164,7 +166,8 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
             color = (torch.empty if tile_rows is None else torch.zeros)(3, H, W, dtype=torch.float32, device=device)
         guess_key = (P, W, H, None if tile_rows is None else tuple(int(v) for v in tile_rows), device.index)
         guess = _binning_guess.get(guess_key, 0)
-        binning = _workspace(_binning_bytes(guess), device) if guess > 0 else None
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        binning = _workspace(_binning_bytes(guess, tiles), device) if guess > 0 else None
         early = None
         if prepare_needs is not None and P > 0 and any(prepare_needs) and caller_grad_enabled():
             needs = tuple(bool(x) for x in prepare_needs)
@@ -198,7 +201,7 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
             if binning is not None and capacity <= guess:
                 capacity = R                                   # the guessed workspace covered the first chunk, a later one did not fit
         while not done:
-            need = _binning_bytes(capacity)
+            need = _binning_bytes(capacity, tiles)
             if binning is None or binning.numel() < need:
                 binning = _workspace(need, device)
             plan.binning_capacity = capacity
@@ -213,6 +216,7 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
         _binning_guess[guess_key] = capacity
         if len(_binning_guess) > 64:
             _binning_guess.pop(next(iter(_binning_guess)))
+    fr.color = color               # the blend backward walks the lists front to back and needs the final pixel
     return color, fr.radii, fr
 
 
@@ -229,7 +233,7 @@ def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.T
     with torch.cuda.device(fr.device):
         # one 48-B gradient row per EMITTED instance: backward-only scratch, returned to the allocator on exit
         rows = _workspace(N.backward_rows_size(fr.desc, fr.plan), fr.device)
-        N.backward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, rows, fr.plan, grad_color, screen,
+        N.backward_render(fr.desc, fr.cam, fr.geom_ws, fr.binning_ws, fr.image_ws, rows, fr.plan, fr.color, grad_color, screen,
                           fr.device)
         fr.plan.screen_prezeroed = 0
     return screen[:P]
@@ -319,7 +323,8 @@ def _dump(path, payload):
         pass
 
 
-_FRAME_TENSORS = ("geom_ws", "binning_ws", "image_ws", "radii")
+_FRAME_TENSORS = ("geom_ws", "binning_ws", "image_ws", "radii", "color")       # color: the forward's OUTPUT, saved like the upstream
+# extension saves its buffers — a caller that modifies the rendered image in place before backward() gets autograd's usual error
 
 
 def _stash_frame(ctx, frame):
@@ -338,10 +343,10 @@ def _stash_frame(ctx, frame):
 def _unstash_frame(ctx):
     fr = ctx.frame
     saved = ctx.saved_tensors                      # raises if the graph's buffers were already freed
-    for n, t in zip(_FRAME_TENSORS, saved[:4]):
+    for n, t in zip(_FRAME_TENSORS, saved[:5]):
         setattr(fr, n, t)
-    it = iter(saved[8:])
-    fr.keep = (tuple(saved[4:8]),) + tuple(next(it) if m else None for m in ctx.frame_keep_mask)
+    it = iter(saved[9:])
+    fr.keep = (tuple(saved[5:9]),) + tuple(next(it) if m else None for m in ctx.frame_keep_mask)
     return fr
 
 

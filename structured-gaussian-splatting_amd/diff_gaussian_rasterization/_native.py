@@ -59,12 +59,12 @@ class FramePlan(C.Structure):
 class DebugViews(C.Structure):
     _fields_ = [("splat_records", C.c_void_p), ("tiles_touched", C.c_void_p), ("depth_order", C.c_void_p),
                 ("point_offsets", C.c_void_p), ("clamped", C.c_void_p), ("sorted_gaussian", C.c_void_p),
-                ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("tile_work", C.c_void_p),
-                ("tile_order", C.c_void_p)]
+                ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("tile_walk", C.c_void_p),
+                ("bwd_units", C.c_void_p), ("bwd_unit_count", C.c_void_p), ("bwd_unit_capacity", C.c_uint64)]
 
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess", "gsr_forward",
-           "gsr_forward_render", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_backward_geom_rows", "gsr_frame_arrays", "gsr_exchange_rows_gather", "gsr_exchange_rows_scatter", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
+           "gsr_forward_render", "gsr_bwd_segment_entries", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_backward_geom_rows", "gsr_frame_arrays", "gsr_exchange_rows_gather", "gsr_exchange_rows_scatter", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows", "gsr_loss_l1_backward",
            "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_adam_step_split", "gsr_densify_stats",
            "gsr_activations_forward", "gsr_activations_backward")
@@ -187,11 +187,21 @@ def backward_prepare(desc, g: Gaussians, plan: FramePlan, screen_grads, grads: G
                                        _stream(device)), "gsr_backward_prepare")
 
 
-def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, rows_ws, plan: FramePlan, dL_dcolor, screen_grads,
+def backward_render(desc, cam: Camera, geom_ws, binning_ws, image_ws, rows_ws, plan: FramePlan, out_color, dL_dcolor, screen_grads,
                     device):
     _check(load().gsr_backward_render(C.byref(desc), C.byref(cam), _ptr(geom_ws), _ptr(binning_ws), _ptr(image_ws),
-                                      _ptr(rows_ws), C.byref(plan), _ptr(dL_dcolor), _ptr(screen_grads), _stream(device)),
+                                      _ptr(rows_ws), C.byref(plan), _ptr(out_color), _ptr(dL_dcolor), _ptr(screen_grads), _stream(device)),
            "gsr_backward_render")
+
+
+_SEG = [0]
+
+
+def bwd_segment_entries() -> int:
+    """List entries per work unit of the blend backward (a build constant of the library)."""
+    if not _SEG[0]:
+        _SEG[0] = int(load().gsr_bwd_segment_entries())
+    return _SEG[0]
 
 
 def backward_geom(desc, cam: Camera, g: Gaussians, radii, geom_ws, screen_grads, g0, g1, grads: Grads, device,
@@ -268,8 +278,10 @@ def debug_views(desc, geom_ws, binning_ws, image_ws, plan: FramePlan) -> dict:
         ranges=view(image_ws, v.ranges, MAX_CHUNKS * Tn * 8, torch.int32, (MAX_CHUNKS, Tn, 2)),
         final_T=view(image_ws, v.final_T, N * 4, torch.float32, (desc.height, desc.width)),
         n_contrib=view(image_ws, v.n_contrib, N * 4, torch.int32, (desc.height, desc.width)),
-        tile_work=view(image_ws, v.tile_work, Tn * 4, torch.int32, (Tn,)),
-        tile_order=view(image_ws, v.tile_order, Tn * 4, torch.int32, (Tn,)))
+        tile_walk=view(image_ws, v.tile_walk, MAX_CHUNKS * Tn * 4, torch.int32, (MAX_CHUNKS, Tn)),
+        # (tile | chunk << 24, segment | last << 31) per work unit of the blend backward; the count lives on the device
+        bwd_units=view(binning_ws, v.bwd_units, int(v.bwd_unit_capacity) * 8, torch.int32, (int(v.bwd_unit_capacity), 2)),
+        bwd_unit_count=view(binning_ws, v.bwd_unit_count, 4, torch.int32, (1,)))
 
 
 def profile_enable(on: bool):

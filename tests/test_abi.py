@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(native):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gsrast.h but not exported"
     assert set(native.EXPORTS) == declared
-    assert lib.gsr_version() == 11
+    assert lib.gsr_version() == 12
 
 
 def test_argument_validation_without_gpu(native):
@@ -40,7 +40,9 @@ def test_argument_validation_without_gpu(native):
     ok = native.make_desc(1000, 3, 16, 100, 60, 0.5, 0.5, 1.0, False, False)
     gb, ib = native.workspace_sizes(ok)
     assert gb >= 1000 * 57 and ib >= 100 * 60 * 8 + 7 * 4 * 8
-    assert 5000 * 4 * 6 <= native.binning_size(ok, 5000) < 5000 * 4 * 6 + 4096
+    # six u32 and one flag byte per instance, one 4 KB checkpoint per segment of them, the blend backward's unit list
+    seg = native.bwd_segment_entries()
+    assert 5000 * 25 + (5000 // seg) * 4096 <= native.binning_size(ok, 5000) < 5000 * 25 + (5000 // seg + 2) * 4096 + 8 * (5000 // seg + 8 * 28 + 1) + 4096
     # backward-only gradient rows: 48 B per EMITTED instance; the emission bound when the count stayed on the device
     plan = native.FramePlan(); plan.instances_emitted = 1234
     assert 1234 * 48 <= native.backward_rows_size(ok, plan) < 1234 * 48 + 512
@@ -93,7 +95,7 @@ def test_python_mirror_of_binning_size_matches_the_library():
     from diff_gaussian_rasterization import _native as N
     desc = N.make_desc(1000, 3, 16, 640, 480, 0.5, 0.5, 1.0, False, False)
     for n in (0, 1, 63, 64, 65, 1000, 123_457, 28_201_899, 492_421_683):
-        assert dgr._binning_bytes(n) == N.binning_size(desc, n), n
+        assert dgr._binning_bytes(n, 40 * 30) == N.binning_size(desc, n), n
     plan = N.FramePlan()
     for chunks, first, R in ((1, 500, 500), (3, 2_000_000, 28_000_000), (2, 900_000, 1_000_000), (4, 10, 5_000_000_000)):
         plan.num_chunks, plan.num_rendered = chunks, R

@@ -1306,18 +1306,60 @@ def test_one_call_forward_falls_back_when_the_guessed_workspace_is_too_small():
     dgr._binning_guess.clear()
 
 
+def _check_bwd_units(fr, v, W, H, rows):
+    """The blend backward's unit list against the frame: every (tile, chunk) pair whose range is not empty is covered by the
+    segments 0 .. ceil(walk / SEG) - 1 exactly once (one segment, flagged last, when nothing is walked), the last segment of
+    each pair carries the flag, and the list is ordered longest unit first (full segments, then partial ones by length)."""
+    from diff_gaussian_rasterization import _native as N
+    SEG = N.bwd_segment_entries()
+    Gx, Gy = (W + 15) // 16, (H + 15) // 16
+    ty0, ty1 = (0, Gy) if rows is None else rows
+    n_units = int(v["bwd_unit_count"][0])
+    units = v["bwd_units"][:n_units].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    tile, chunk = units[:, 0] & ((1 << 24) - 1), units[:, 0] >> 24
+    seg, last = units[:, 1] & 0x7FFFFFFF, units[:, 1] >> 31
+    rng = v["ranges"].long().cpu().numpy()[:fr.plan.chunks_run]
+    lens = rng[..., 1] - rng[..., 0]
+    walk = np.minimum(v["tile_walk"].long().cpu().numpy()[:fr.plan.chunks_run], lens)
+    # what the forward recorded = the tile's deepest contributor in that chunk (exact for the chunk a pixel's final record
+    # names; with several chunks the earlier ones' depths are a lower bound)
+    enc = v["n_contrib"].long().cpu().numpy()
+    c_last, n_last = (enc >> 26) - 1, enc & ((1 << 26) - 1)
+    for c in range(fr.plan.chunks_run):
+        d = np.zeros((Gy * 16, Gx * 16), np.int64)
+        d[:H, :W] = np.where(c_last == c, n_last, 0)
+        want = d.reshape(Gy, 16, Gx, 16).max(axis=(1, 3)).reshape(-1)
+        got = np.where(lens[c] > 0, walk[c], 0)
+        inside = np.zeros(Gx * Gy, bool); inside[ty0 * Gx:ty1 * Gx] = True
+        if fr.plan.chunks_run == 1:
+            np.testing.assert_array_equal(got[inside], want[inside])
+        else:
+            assert np.all(got[inside] >= want[inside])
+    nseg = np.where(lens > 0, np.maximum((walk + SEG - 1) // SEG, 1), 0)
+    nseg[:, :ty0 * Gx] = 0; nseg[:, ty1 * Gx:] = 0
+    assert n_units == int(nseg.sum()) and n_units > 0
+    seen = set(zip(chunk.tolist(), tile.tolist(), seg.tolist()))
+    assert len(seen) == n_units                                               # no unit twice
+    assert np.all(seg < nseg[chunk, tile])                                    # ... and none outside its pair: so every one exactly once
+    np.testing.assert_array_equal(last, (seg == nseg[chunk, tile] - 1).astype(np.int64))
+    length = np.minimum(walk[chunk, tile] - seg * SEG, SEG)
+    assert np.all(length[1:] <= length[:-1]) and length.max() > 0
+    return n_units
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,H,P,rows", [(320, 208, 6000, None), (320, 208, 6000, (3, 9)), (2560, 1616, 40_000, None),
-                                          (4096, 2176, 40_000, None)])
-def test_backward_launch_order_is_a_permutation_longest_tile_first(W, H, P, rows):
-    """K7 runs the slab's tiles longest first (k_tile_order): the order is a permutation of the slab's tiles, the work the
-    forward recorded per tile equals the deepest contributor over the tile's pixels (summed over the chunks), and it does not
-    increase along the order at the resolution of the sort's bins (9 bits of the longest tile's work).  16 160 tiles in the
-    third case (the 32-per-thread instantiation), 34 816 in the fourth: beyond what a block keeps in registers.  The order never changes a value: the gradients equal those of a
-    launch in tile order (GSR_BWD_TILE_ORDER is read once per process, so that comparison lives in tools/ab.sh)."""
+                                        (480, 320, 260_000, None)])
+def test_backward_work_units_cover_every_walked_entry_once_longest_first(W, H, P, rows):
+    """K7 runs one wave per (tile, chunk, segment) unit (csrc/gsr_bwd_units.h).  The last case is the frame with an uncovered
+    half of test_frame_with_an_uncovered_region_...: several chunks, chunk-start checkpoints."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _native as N
-    scene = S.make_scene(P, W, H, 1, 77, scale_lo=0.004, scale_hi=0.05)
+    if P == 260_000:
+        scene = S.make_scene(P, W, H, 1, 91, scale_lo=0.01, scale_hi=0.07)
+        scene.means3D[:, 1] = -scene.means3D[:, 1].abs() - 0.02 * scene.means3D[:, 2]
+    else:
+        scene = S.make_scene(P, W, H, 1, 77, scale_lo=0.004, scale_hi=0.05)
     kw = raster_kwargs(scene, S.make_camera(W, H))
     rs, inp = _settings(kw), _inputs(kw, False)
     args = (inp["means3D"], inp["shs"], None, inp["opacities"], inp["scales"], inp["rotations"], None, rs)
@@ -1326,38 +1368,18 @@ def test_backward_launch_order_is_a_permutation_longest_tile_first(W, H, P, rows
     dgr.rasterize_backward_screen(fr, g)
     torch.cuda.synchronize()
     v = N.debug_views(fr.desc, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan)
-    Gx, Gy = (W + 15) // 16, (H + 15) // 16
-    ty0, ty1 = (0, Gy) if rows is None else rows
-    n = (ty1 - ty0) * Gx
-    order = v["tile_order"][:n].long().cpu().numpy()
-    assert sorted(order.tolist()) == list(range(n))
-    work = v["tile_work"].long().cpu().numpy()[ty0 * Gx:ty1 * Gx]
-    enc = v["n_contrib"].long().cpu().numpy()
-    c_last, n_last = (enc >> 26) - 1, enc & ((1 << 26) - 1)
-    lens = v["ranges"].long().cpu().numpy()[:fr.plan.chunks_run]
-    lens = lens[..., 1] - lens[..., 0]
-    want = np.zeros(n, np.int64)
-    for c in range(fr.plan.chunks_run):
-        d = np.zeros((Gy * 16, Gx * 16), np.int64)
-        d[:H, :W] = np.where(c_last == c, n_last, 0)
-        want += d.reshape(Gy, 16, Gx, 16).max(axis=(1, 3)).reshape(-1)[ty0 * Gx:ty1 * Gx]
-    # (a pixel's final record names its LAST chunk only: with several chunks the earlier ones' depths are a lower bound)
-    if fr.plan.chunks_run == 1:
-        np.testing.assert_array_equal(work, want)
-    else:
-        assert np.all(work >= want)
-    assert work.max() > 0
-    shift = max(int(work.max()).bit_length() - 9, 0)
-    along = work[order] >> shift
-    assert np.all(along[1:] <= along[:-1])
+    n = _check_bwd_units(fr, v, W, H, rows)
+    if P == 260_000:
+        assert fr.plan.chunks_run >= 2
+    print(f"{W}x{H} P={P} rows={rows}: {n} units, {fr.plan.chunks_run} chunk(s)")
 
 
 @pytest.mark.gpu
-def test_zero_fill_carries_the_backward_launch_order():
+def test_zero_fill_carries_the_backward_unit_list():
     """A training frame (gradients wanted, sparse geometry backward, binning workspace guessed from the previous frame) runs as
-    ONE gsr_forward whose zero fill also sorts the tiles for K7 (k_zero_segments<true>, block 0): plan.tile_order_ready is set,
-    gsr_backward_render launches no k_tile_order, the order is a valid longest-first permutation and the screen-space
-    gradients equal, bit for bit, those of the same frame run without the early fill (its own k_tile_order launch)."""
+    ONE gsr_forward whose zero fill also builds K7's unit list (k_zero_segments<true>, block 0): plan.tile_order_ready is set,
+    gsr_backward_render launches no k_bwd_units, the list is valid and the screen-space gradients equal, bit for bit, those of
+    the same frame run without the early fill (its own k_bwd_units launch)."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _native as N
     W, H, P = 640, 368, 200_000
@@ -1368,8 +1390,11 @@ def test_zero_fill_carries_the_backward_launch_order():
     needs = (True, True, True, False, True, True, True, False)
     g = S.make_grad_image(W, H, 6).to(DEV)
     _, _, plain = dgr.rasterize_forward(*args)                                    # also leaves the workspace guess behind
+    N.profile_enable(True)
     want = dgr.rasterize_backward_screen(plain, g).clone()
-    assert plain.plan.tile_order_ready == 0
+    torch.cuda.synchronize()
+    prof = N.profile_read(); N.profile_enable(False)
+    assert plain.plan.tile_order_ready == 0 and "bwd_units" in prof
     _, _, fr = dgr.rasterize_forward(*args, prepare_needs=needs)
     assert int(fr.plan.chunk_rank_begin[fr.plan.chunks_run]) * 4 < P, "the scene must take the sparse path"
     assert fr.pre is not None and fr.pre["grads"].prezeroed == 1 and fr.plan.tile_order_ready == 1
@@ -1378,15 +1403,9 @@ def test_zero_fill_carries_the_backward_launch_order():
     got = dgr.rasterize_backward_screen(fr, g)
     torch.cuda.synchronize()
     prof = N.profile_read(); N.profile_enable(False)
-    assert "render_bwd" in prof and "tile_order" not in prof, sorted(prof)
+    assert "render_bwd" in prof and "bwd_units" not in prof, sorted(prof)
     v = N.debug_views(fr.desc, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan)
-    n = ((W + 15) // 16) * ((H + 15) // 16)
-    order = v["tile_order"][:n].long().cpu().numpy()
-    assert sorted(order.tolist()) == list(range(n))
-    work = v["tile_work"].long().cpu().numpy()
-    shift = max(int(work.max()).bit_length() - 9, 0)
-    along = work[order] >> shift
-    assert work.max() > 0 and np.all(along[1:] <= along[:-1])
+    _check_bwd_units(fr, v, W, H, None)
     n_pref = int(fr.plan.chunk_rank_begin[fr.plan.chunks_run])
     pref = N.frame_arrays(fr.desc, fr.geom_ws)[1][:n_pref].long()
     assert torch.equal(got[pref], want[pref])                                     # (rows outside the binned prefix: never cleared here)
