@@ -27,52 +27,56 @@ __device__ __forceinline__ float fast_exp(float x)
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// Nine independent wave sums in ONE asm block, step-major: v_add_f32_dpp v, v, v <ctrl> computes
-// v = dpp(v) + v (lanes whose DPP source does not exist are disabled and keep v, i.e. add 0).  The same
-// register's next step is nine instructions later, which covers the VALU-write -> DPP-read wait states; the
-// leading s_nop covers the instruction that produced the inputs.  Totals land in lane 63.
-#define GSR_DPP9(ctrl)                                                                                   \
-    "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
-    "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
-    "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
-    "v_add_f32_dpp %3, %3, %3 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
-    "v_add_f32_dpp %4, %4, %4 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
-    "v_add_f32_dpp %5, %5, %5 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
-    "v_add_f32_dpp %6, %6, %6 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
-    "v_add_f32_dpp %7, %7, %7 " ctrl " row_mask:0xf bank_mask:0xf\n\t"                                   \
-    "v_add_f32_dpp %8, %8, %8 " ctrl " row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ void wave_sum9_to_lane63(float &a, float &b, float &c, float &d, float &e, float &f_, float &g,
-                                                    float &h, float &i)
-{
-    asm volatile("s_nop 1\n\t" GSR_DPP9("row_shr:1") GSR_DPP9("row_shr:2") GSR_DPP9("row_shr:4") GSR_DPP9("row_shr:8")
-                     GSR_DPP9("row_bcast:15") GSR_DPP9("row_bcast:31") "s_nop 1"
-                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f_), "+v"(g), "+v"(h), "+v"(i));
-}
-
-// The same for TWO splats at once: a[] holds the first splat's nine lane sums, b[] the second's.  v_permlane32_swap trades
-// a's upper 32 lanes for b's lower 32, so a + b is "first splat, lanes l and l + 32" in the lower half of the wave and
-// "second splat" in the upper half; four row steps and row_bcast:15 finish both (row_bcast also adds lane 31's partial sum
-// into row 2: harmless, lane 63 reads row 2's lane 47 as it was before the instruction).  Totals: lane 31 (first), lane 63
-// (second).
+// Wave reduction of the blend backward: NINE sums per splat over the 64 lanes, TWO splats per call (a[] the first splat's nine
+// lane sums, b[] the second's), as a butterfly that halves the data with the lanes instead of carrying all nine values through
+// every step:
+//   1. v_permlane32_swap trades a's upper 32 lanes for b's lower 32: a + b = "first splat, lanes l and l + 32" in the lower half
+//      of the wave and "second splat" in the upper half                                             (9 swaps, 9 adds -> 9 values on 32 lanes)
+//   2. v_permlane16_swap on the register pairs (k, k + 5) trades odd rows of one for even rows of the other: the sum holds value k
+//      in a half's even row and value k + 5 in its odd row (value 4's partner is a zero)            (5 swaps, 5 adds -> 5 values on 16 lanes)
+//   3. inside a row of 16 lanes, DPP adds with BANK masks: lane i + lane i ^ 8 (row_ror:8) with values (0, 3) and (1, 4) sharing a
+//      register by row half; lane i + lane 7 - i (row_half_mirror) with (0 | 1 | 3 | 4) sharing one register by bank; the last two
+//      steps inside each quad                                                                        (5 + 3 + 4 DPP adds)
+// 42 instructions per two splats instead of 63 for two nine-value trees.  Where the totals land (h = lane & 31; first splat in
+// lanes 0..31, second in 32..63; every lane of a quad holds the quad's value):
+//   a[0]: quad of h = 0: value 0, h = 4: 1, h = 8: 3, h = 12: 4, h = 16: 5, h = 20: 6, h = 24: 8;   a[2]: h < 16: value 2, h >= 16: 7;
+//   a[1]: quad of h = 0: value 1 (a copy, so that one lane holds values 0, 1 and 2).
+// DPP hazard (a VALU write followed by a DPP read of the same register needs two wait states) is covered by the order and s_nops.
 __device__ __forceinline__ void wave_sum9_two(float (&a)[9], float (&b)[9])
 {
-    // one asm block: the swaps work in place on both operands (b is dead afterwards), so no copies and no per-swap wait
-    // states; the leading s_nop covers the instructions that produced the inputs
-#define GSR_SWAP(i, j) "v_permlane32_swap_b32 %" #i ", %" #j "\n\t"
+#define GSR_SWAP32(i, j) "v_permlane32_swap_b32 %" #i ", %" #j "\n\t"
+#define GSR_SWAP16(i, j) "v_permlane16_swap_b32 %" #i ", %" #j "\n\t"
 #define GSR_ADD(i, j) "v_add_f32 %" #i ", %" #i ", %" #j "\n\t"
+#define GSR_DPP(d, s_, ctrl, bank) "v_add_f32_dpp %" #d ", %" #s_ ", %" #s_ " " ctrl " row_mask:0xf bank_mask:" bank "\n\t"
     asm volatile("s_nop 1\n\t"
-                 GSR_SWAP(0, 9) GSR_SWAP(1, 10) GSR_SWAP(2, 11) GSR_SWAP(3, 12) GSR_SWAP(4, 13) GSR_SWAP(5, 14) GSR_SWAP(6, 15)
-                 GSR_SWAP(7, 16) GSR_SWAP(8, 17)
-                 GSR_ADD(0, 9) GSR_ADD(1, 10) GSR_ADD(2, 11) GSR_ADD(3, 12) GSR_ADD(4, 13) GSR_ADD(5, 14) GSR_ADD(6, 15)
-                 GSR_ADD(7, 16) GSR_ADD(8, 17)
-                 "s_nop 1\n\t" GSR_DPP9("row_shr:1") GSR_DPP9("row_shr:2") GSR_DPP9("row_shr:4") GSR_DPP9("row_shr:8")
-                     GSR_DPP9("row_bcast:15") "s_nop 1"
+                 GSR_SWAP32(0, 9) GSR_SWAP32(1, 10) GSR_SWAP32(2, 11) GSR_SWAP32(3, 12) GSR_SWAP32(4, 13) GSR_SWAP32(5, 14)
+                 GSR_SWAP32(6, 15) GSR_SWAP32(7, 16) GSR_SWAP32(8, 17)
+                 GSR_ADD(0, 9) "v_mov_b32 %9, 0\n\t" GSR_ADD(1, 10) GSR_ADD(2, 11) GSR_ADD(3, 12) GSR_ADD(4, 13) GSR_ADD(5, 14)
+                 GSR_ADD(6, 15) GSR_ADD(7, 16) GSR_ADD(8, 17)
+                 "s_nop 1\n\t"
+                 GSR_SWAP16(0, 5) GSR_SWAP16(1, 6) GSR_SWAP16(2, 7) GSR_SWAP16(3, 8) GSR_SWAP16(4, 9)
+                 GSR_ADD(0, 5) GSR_ADD(1, 6) GSR_ADD(2, 7) GSR_ADD(3, 8) GSR_ADD(4, 9)
+                 "s_nop 1\n\t"
+                 GSR_DPP(0, 0, "row_ror:8", "0x3") GSR_DPP(0, 3, "row_ror:8", "0xc")
+                 GSR_DPP(1, 1, "row_ror:8", "0x3") GSR_DPP(1, 4, "row_ror:8", "0xc")
+                 GSR_DPP(2, 2, "row_ror:8", "0xf")
+                 "s_nop 0\n\t"
+                 GSR_DPP(0, 0, "row_half_mirror", "0x5") "s_nop 0\n\t" GSR_DPP(0, 1, "row_half_mirror", "0xa")
+                 GSR_DPP(2, 2, "row_half_mirror", "0xf")
+                 "s_nop 1\n\t"
+                 GSR_DPP(0, 0, "quad_perm:[1,0,3,2]", "0xf") GSR_DPP(2, 2, "quad_perm:[1,0,3,2]", "0xf")
+                 "s_nop 1\n\t"
+                 GSR_DPP(0, 0, "quad_perm:[2,3,0,1]", "0xf") GSR_DPP(2, 2, "quad_perm:[2,3,0,1]", "0xf")
+                 "s_nop 1\n\t"
+                 "v_mov_b32_dpp %1, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
                  : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
                    "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]));
-#undef GSR_SWAP
+#undef GSR_SWAP32
+#undef GSR_SWAP16
 #undef GSR_ADD
+#undef GSR_DPP
 }
-#undef GSR_DPP9
 
 __device__ __forceinline__ int wave_max_uniform(int v)
 {
@@ -122,6 +126,11 @@ __device__ __forceinline__ unsigned stage_batch(float4 *sh_rec, int lane, int n,
 // un-finalised colour in out_color itself; the background term is added exactly once, when the tile
 // closes or after the last chunk.
 //
+// The alpha >= 1/255 test (A.8) is taken on the exponent: lp = log2(opacity exp(power)) < log2(1/255).  Forward and backward use
+// the same constant on the same lp, so they agree on every pixel; against alpha = opacity * exp(power) < 1/255 in exact
+// arithmetic the two rules differ only where alpha sits within rounding of the threshold (the oracle's fragile band).
+constexpr float kLog2AlphaMin = -7.99435343685886f;      // log2(1 / 255)
+
 // Per pixel: Tl = live transmittance (0 once the pixel has taken the cut-off), Tf = transmittance to report (frozen at
 // the cut-off), colour, last contributor.  A rejected splat runs the same arithmetic with alpha = 0, which leaves
 // everything unchanged, so the only selects are on alpha, on the stop decision and on the contributor index.
@@ -134,11 +143,11 @@ template <int MODE>          // 3: both quadrants of the pair (packed), 1: the l
 __device__ __forceinline__ void fwd_pair(v2f lp, float lop, float cr, float cg, float cb, int contributor, FwdPair &P)
 {
     if constexpr (MODE == 3) {
-        const float alpha0 = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(lp[0]));
-        const float alpha1 = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(lp[1]));
-        const bool keep0 = !(lp[0] > lop) && !(alpha0 < (float)GSR_ALPHA_MIN);      // power > 0  <=>  lp > lop
-        const bool keep1 = !(lp[1] > lop) && !(alpha1 < (float)GSR_ALPHA_MIN);
-        const v2f ae = {keep0 ? alpha0 : 0.f, keep1 ? alpha1 : 0.f};
+        const bool keep0 = !(lp[0] > lop) && !(lp[0] < kLog2AlphaMin);      // power > 0  <=>  lp > lop;  alpha < 1/255  <=>  lp < log2(1/255)
+        const bool keep1 = !(lp[1] > lop) && !(lp[1] < kLog2AlphaMin);
+        // a rejected pixel gets lp = -inf: exp2 gives alpha = 0 by itself (one select per pixel, in front of the exponential)
+        const v2f ae = {fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep0 ? lp[0] : -INFINITY)),
+                        fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep1 ? lp[1] : -INFINITY))};
         const v2f test_T = P.Tl * (1.f - ae);                      // == Tl when rejected, 0 when already done
         const v2f aT = ae * P.Tl;
         const bool stop0 = test_T[0] < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
@@ -151,9 +160,8 @@ __device__ __forceinline__ void fwd_pair(v2f lp, float lop, float cr, float cg, 
         P.last1 = (keep1 && !stop1) ? contributor : P.last1;
     } else {
         constexpr int e = MODE - 1;
-        const float alpha = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(lp[e]));
-        const bool keep = !(lp[e] > lop) && !(alpha < (float)GSR_ALPHA_MIN);
-        const float ae = keep ? alpha : 0.f;
+        const bool keep = !(lp[e] > lop) && !(lp[e] < kLog2AlphaMin);
+        const float ae = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep ? lp[e] : -INFINITY));
         const float test_T = P.Tl[e] * (1.f - ae);
         const bool stop = test_T < (float)GSR_T_CUTOFF;
         const float w = stop ? 0.f : ae * P.Tl[e];
@@ -367,45 +375,85 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
 // the conic enters through the pre-scaled record fields directly: cA = -2 ln2 qA, cB = -ln2 qB, cC = -2 ln2 qC, so
 // -(tx cA + ty cB) = ln2 (2 qA tx + qB ty): the factor ln2 goes into the row store.
 struct BwdSplat {            // wave-uniform per-splat values
-    float lop, cr, cg, cb, qA2, qB, qC2;       // qA2 = 2 qA, qC2 = 2 qC
+    float lop, cr, cg, cb;
 };
 struct BwdPair {             // state of a lane's two pixels in one pair of quadrants (left, right)
-    v2f T, D, Q, dpr, dpg, dpb;        // transmittance in front of the current splat, colour prefix . dL/dpix, final pixel . dL/dpix, dL/dpix
+    v2f T, E, dpr, dpg, dpb;           // transmittance in front of the current splat; E = Q - D: what everything behind the current
+                                       // splat (and the background) still adds to <pixel, dL/dpix>; dL/dpix
     int limit0, limit1;                // contributors of the current chunk each pixel takes part in
 };
-struct BwdAcc { v2f S0, S1, S2, S3, S4, S5, S6, S7, S8; };
+// the lane's partial sums of one splat, per pair element: X = sum tA dx, Y = sum tA dy (dL/dmean2D = ln2 (2 qA X + qB Y, 2 qC Y + qB X):
+// formed once per splat by the lane that stores the row), S2..S4 the conic's, S5 the opacity's, S6..S8 the colour's
+struct BwdAcc { v2f X, Y, S2, S3, S4, S5, S6, S7, S8; };
 __device__ __forceinline__ float add_halves(v2f v)
 {
     float r;
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(v[0]), "v"(v[1]));
     return r;
-}     // the lane's nine partial sums of one splat, per pair element
+}
 
+template <int MODE>          // 3: both quadrants of the pair (packed), 1: the left one only, 2: the right one only
 __device__ __forceinline__ bool bwd_pair(const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
 {
-    const float araw0 = __builtin_amdgcn_exp2f(lp[0]), araw1 = __builtin_amdgcn_exp2f(lp[1]);      // = opacity * G
-    const float alpha0 = fminf((float)GSR_ALPHA_MAX, araw0), alpha1 = fminf((float)GSR_ALPHA_MAX, araw1);
-    const bool valid0 = (pos < P.limit0) && !(lp[0] > sp.lop) && !(alpha0 < (float)GSR_ALPHA_MIN);      // power > 0 <=> lp > lop
-    const bool valid1 = (pos < P.limit1) && !(lp[1] > sp.lop) && !(alpha1 < (float)GSR_ALPHA_MIN);
-    const v2f ae = {valid0 ? alpha0 : 0.f, valid1 ? alpha1 : 0.f};
-    const v2f ga = {valid0 ? araw0 : 0.f, valid1 ? araw1 : 0.f};
-    const v2f one_m = 1.f - ae;
-    const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
-    const v2f cdp = sp.cr * P.dpr + sp.cg * P.dpg + sp.cb * P.dpb;      // <c_i, dL/dpix>
-    const v2f w = ae * P.T;                                              // d colour / d rgb
-    P.D += w * cdp;                                                      // prefix including this splat
-    const v2f dL_dalpha = P.T * cdp - (P.Q - P.D) * inv1ma;
-    P.T = P.T * one_m;                                                   // exactly the forward's update
-    const v2f tA = dL_dalpha * ga;
-    const v2f tx = tA * dx, ty = tA * dy;
-    A.S0 += sp.qA2 * tx + sp.qB * ty;
-    A.S1 += sp.qC2 * ty + sp.qB * tx;
-    A.S2 += tx * dx;
-    A.S3 += tx * dy;
-    A.S4 += ty * dy;
-    A.S5 += tA;
-    A.S6 += w * P.dpr; A.S7 += w * P.dpg; A.S8 += w * P.dpb;
-    return valid0 || valid1;
+    if constexpr (MODE == 3) {
+        const bool valid0 = (pos < P.limit0) && !(lp[0] > sp.lop) && !(lp[0] < kLog2AlphaMin);      // power > 0 <=> lp > lop
+        const bool valid1 = (pos < P.limit1) && !(lp[1] > sp.lop) && !(lp[1] < kLog2AlphaMin);
+        // a rejected pixel gets lp = -inf: ga = opacity * G and alpha come out 0 by themselves
+        const v2f ga = {__builtin_amdgcn_exp2f(valid0 ? lp[0] : -INFINITY), __builtin_amdgcn_exp2f(valid1 ? lp[1] : -INFINITY)};
+        const v2f ae = {fminf((float)GSR_ALPHA_MAX, ga[0]), fminf((float)GSR_ALPHA_MAX, ga[1])};
+        const v2f one_m = 1.f - ae;
+        const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
+        const v2f cdp = sp.cr * P.dpr + sp.cg * P.dpg + sp.cb * P.dpb;      // <c_i, dL/dpix>
+        const v2f w = ae * P.T;                                              // d colour / d rgb
+        P.E -= w * cdp;                                                      // this splat's own share leaves the remainder
+        const v2f dL_dalpha = P.T * cdp - P.E * inv1ma;
+        P.T = P.T * one_m;                                                   // exactly the forward's update
+        const v2f tA = dL_dalpha * ga;
+        const v2f tx = tA * dx, ty = tA * dy;
+        A.X += tx; A.Y += ty;
+        A.S2 += tx * dx;
+        A.S3 += tx * dy;
+        A.S4 += ty * dy;
+        A.S5 += tA;
+        A.S6 += w * P.dpr; A.S7 += w * P.dpg; A.S8 += w * P.dpb;
+        return valid0 || valid1;
+    } else {
+        // one wanted quadrant: plain fp32 on that element only
+        constexpr int e = MODE - 1;
+        const bool valid = (pos < (e ? P.limit1 : P.limit0)) && !(lp[e] > sp.lop) && !(lp[e] < kLog2AlphaMin);
+        const float ga = __builtin_amdgcn_exp2f(valid ? lp[e] : -INFINITY);
+        const float ae = fminf((float)GSR_ALPHA_MAX, ga);
+        const float one_m = 1.f - ae;
+        const float inv1ma = fast_rcp(one_m);
+        const float cdp = sp.cr * P.dpr[e] + sp.cg * P.dpg[e] + sp.cb * P.dpb[e];
+        const float w = ae * P.T[e];
+        P.E[e] -= w * cdp;
+        const float dL_dalpha = P.T[e] * cdp - P.E[e] * inv1ma;
+        P.T[e] = P.T[e] * one_m;
+        const float tA = dL_dalpha * ga;
+        const float tx = tA * dx[e], ty = tA * dy;
+        A.X[e] += tx; A.Y[e] += ty;
+        A.S2[e] += tx * dx[e];
+        A.S3[e] += tx * dy;
+        A.S4[e] += ty * dy;
+        A.S5[e] += tA;
+        A.S6[e] += w * P.dpr[e]; A.S7[e] += w * P.dpg[e]; A.S8[e] += w * P.dpb[e];
+        return valid;
+    }
+}
+
+// mp = the pair's two mask bits.  GSR_BWD_SINGLE = 0: a pair always runs packed (a clear mask bit means that no pixel of that
+// quadrant accepts the splat, so its lanes of the packed arithmetic find `valid` false on their own).
+#ifndef GSR_BWD_SINGLE
+#define GSR_BWD_SINGLE 0      // measured at cfg3n: 641 us with the single-quadrant variants, 616 without (code size, 7 spilled registers)
+#endif
+__device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
+{
+#if GSR_BWD_SINGLE
+    if (mp == 1u) return bwd_pair<1>(sp, lp, dx, dy, pos, P, A);
+    if (mp == 2u) return bwd_pair<2>(sp, lp, dx, dy, pos, P, A);
+#endif
+    return bwd_pair<3>(sp, lp, dx, dy, pos, P, A);
 }
 
 // The unit list (gsr_bwd_units.h) in its own launch: only when the forward's zero fill did not carry it (k_zero_segments<true>,
@@ -441,6 +489,10 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
     const int lane = threadIdx.x;
     const size_t N = (size_t)f.W * f.H;
     const float half_w = 0.5f * (float)f.W, half_h = 0.5f * (float)f.H;
+    // where this lane's total of the wave reduction goes in a gradient row (store_rows below): float index, factor
+    const int h31 = lane & 31;
+    const int row_off = h31 == 8 ? 3 : h31 == 12 ? 4 : h31 == 16 ? 5 : h31 == 20 ? 6 : h31 == 24 ? 8 : -1;
+    const float row_mul = (h31 == 8 || h31 == 12) ? -0.5f : 1.f;
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
         const uint2 unit = units[u];
         const int tile = (int)(unit.x & ((1u << kUnitTileBits) - 1u)), c = (int)(unit.x >> kUnitTileBits);
@@ -459,7 +511,7 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
         BwdPair P0, P1;
         const float *chk = (sgm > 0) ? ckpt + (size_t)((rng.x + (uint32_t)seg_begin) / kSeg) * kCkptFloats
                                      : (c > 0 ? ckpt_start + ((size_t)(c - 1) * Tn + tile) * kCkptFloats : nullptr);
-        auto load_px = [&](int k, float &Tk, float &Dk, float &Qk, float &r_, float &g_, float &b_, int &limit) {
+        auto load_px = [&](int k, float &Tk, float &Ek, float &r_, float &g_, float &b_, int &limit) {
             const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
             const bool inside = px < f.W && py < f.H;
             const size_t pix = inside ? (size_t)py * f.W + px : 0;
@@ -467,20 +519,22 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
             const int c_last = (enc >> kLastShift) - 1;                              // -1: no contributor at all
             limit = c < c_last ? n_total : (c == c_last ? (enc & ((1 << kLastShift) - 1)) : 0);
             r_ = inside ? dL_dpix[pix] : 0.f; g_ = inside ? dL_dpix[N + pix] : 0.f; b_ = inside ? dL_dpix[2 * N + pix] : 0.f;
-            Qk = inside ? out_color[pix] * r_ + out_color[N + pix] * g_ + out_color[2 * N + pix] * b_ : 0.f;
-            Tk = 1.f; Dk = 0.f;
+            // E = Q - D: the final pixel (background term included) minus the colour in front of the segment, dotted with dL/dpix
+            float er = inside ? out_color[pix] : 0.f, eg = inside ? out_color[N + pix] : 0.f, eb = inside ? out_color[2 * N + pix] : 0.f;
+            Tk = 1.f;
             if (chk) {
                 const float *q = chk + 4 * k * kWave + lane;
                 Tk = q[0];
-                Dk = q[kWave] * r_ + q[2 * kWave] * g_ + q[3 * kWave] * b_;
+                er -= q[kWave]; eg -= q[2 * kWave]; eb -= q[3 * kWave];
             }
+            Ek = er * r_ + eg * g_ + eb * b_;
         };
         {
-            float Ta, Da, Qa, ra, ga, bla, Tb, Db, Qb, rb, gb, blb;
-            load_px(0, Ta, Da, Qa, ra, ga, bla, P0.limit0); load_px(1, Tb, Db, Qb, rb, gb, blb, P0.limit1);
-            P0.T = v2f{Ta, Tb}; P0.D = v2f{Da, Db}; P0.Q = v2f{Qa, Qb}; P0.dpr = v2f{ra, rb}; P0.dpg = v2f{ga, gb}; P0.dpb = v2f{bla, blb};
-            load_px(2, Ta, Da, Qa, ra, ga, bla, P1.limit0); load_px(3, Tb, Db, Qb, rb, gb, blb, P1.limit1);
-            P1.T = v2f{Ta, Tb}; P1.D = v2f{Da, Db}; P1.Q = v2f{Qa, Qb}; P1.dpr = v2f{ra, rb}; P1.dpg = v2f{ga, gb}; P1.dpb = v2f{bla, blb};
+            float Ta, Ea, ra, ga, bla, Tb, Eb, rb, gb, blb;
+            load_px(0, Ta, Ea, ra, ga, bla, P0.limit0); load_px(1, Tb, Eb, rb, gb, blb, P0.limit1);
+            P0.T = v2f{Ta, Tb}; P0.E = v2f{Ea, Eb}; P0.dpr = v2f{ra, rb}; P0.dpg = v2f{ga, gb}; P0.dpb = v2f{bla, blb};
+            load_px(2, Ta, Ea, ra, ga, bla, P1.limit0); load_px(3, Tb, Eb, rb, gb, blb, P1.limit1);
+            P1.T = v2f{Ta, Tb}; P1.E = v2f{Ea, Eb}; P1.dpr = v2f{ra, rb}; P1.dpg = v2f{ga, gb}; P1.dpb = v2f{bla, blb};
         }
         // per quadrant: the wave's last participating contributor
         const int qmax0 = min(walk_end, wave_max_uniform(P0.limit0)), qmax1 = min(walk_end, wave_max_uniform(P0.limit1)),
@@ -501,79 +555,84 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
                 unsigned long long act = __ballot(mymask != 0u);       // splats with work, walked front to back
                 // One splat's pass over the tile: the lane's nine partial sums (both pairs, both pair elements added up).
                 // Returns false when no pixel of the tile accepted the splat (its row is not written).
-                auto splat_pass = [&](int j, float (&s)[9], float &lop) -> bool {
+                auto splat_pass = [&](int j, float (&s)[9]) -> bool {
                     const int pos = base + j;
                     const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mymask, j);
                     const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
                     BwdSplat sp;
                     sp.lop = b.y; sp.cr = b.z; sp.cg = b.w; sp.cb = sh_rec[3 * j + 2].x;
-                    sp.qA2 = 2.f * a.z; sp.qB = a.w; sp.qC2 = 2.f * b.x;
                     const float dxl = a.x - fx0;
                     const v2f dx = {dxl, dxl - 8.f};
                     const v2f axx = a.z * dx * dx + b.y, bx = a.w * dx;       // pre-scaled record: lp = log2(op exp(power))
                     BwdAcc A;
-                    A.S0 = A.S1 = A.S2 = A.S3 = A.S4 = A.S5 = A.S6 = A.S7 = A.S8 = v2f{0.f, 0.f};
+                    A.X = A.Y = A.S2 = A.S3 = A.S4 = A.S5 = A.S6 = A.S7 = A.S8 = v2f{0.f, 0.f};
                     bool any_valid = false;
-                    // a pair runs packed whenever either of its quadrants is wanted: a clear mask bit means that no pixel of that
-                    // quadrant accepts the splat, so its lanes of the packed arithmetic find `valid` false on their own
                     if (m & 3u) {
                         const float dy = a.y - fy0;
-                        any_valid = bwd_pair(sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P0, A);
+                        any_valid = bwd_pair_dispatch(m & 3u, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P0, A);
                     }
                     if (m & 12u) {
                         const float dy = a.y - fy1;
-                        const bool v = bwd_pair(sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P1, A);
+                        const bool v = bwd_pair_dispatch(m >> 2, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P1, A);
                         any_valid = any_valid || v;
                     }
                     if (__ballot(any_valid) == 0ull) return false;
                     // (nine plain adds: left to itself the compiler transposes the pairs with twelve moves to use packed adds)
-                    s[0] = add_halves(A.S0); s[1] = add_halves(A.S1); s[2] = add_halves(A.S2); s[3] = add_halves(A.S3);
+                    s[0] = add_halves(A.X); s[1] = add_halves(A.Y); s[2] = add_halves(A.S2); s[3] = add_halves(A.S3);
                     s[4] = add_halves(A.S4); s[5] = add_halves(A.S5); s[6] = add_halves(A.S6); s[7] = add_halves(A.S7);
                     s[8] = add_halves(A.S8);
-                    lop = sp.lop;
                     return true;
                 };
-                auto store_row = [&](const float (&s)[9], float lop, uint32_t slot_j) {
-                    const float inv_op = __builtin_amdgcn_exp2f(-lop);                  // 1 / opacity
-                    float4 *row = grad_rows + 3 * (size_t)slot_j;
-                    row_valid[slot_j] = 1;                                              // (cleared ahead of the launch; rows nobody writes are never read)
-                    // -(tx cA + ty cB) = ln2 (2 qA tx + qB ty), likewise for y; gA, gB, gC carry the -1/2 of A.9
-                    row[0] = make_float4(s[0] * (0.69314718f * half_w), s[1] * (0.69314718f * half_h), s[2] * -0.5f, s[3] * -0.5f);
-                    row[1] = make_float4(s[4] * -0.5f, s[5] * inv_op, s[6], s[7]);
-                    row[2] = make_float4(s[8], 0.f, 0.f, 0.f);
+                // Rows are stored by the lanes the reduction left the totals in (wave_sum9_two; h = lane & 31): h = 0 holds X, Y and S2
+                // and forms dL/dmean2D from the splat's record, which is still staged (the same batch); five more lanes hold one value
+                // each, h = 16 two.  -(X cA + Y cB) = ln2 (2 qA X + qB Y), likewise for y; gA, gB, gC carry the -1/2 of A.9.
+                auto store_rows = [&](const float (&s)[9], int j, uint32_t slot_j) {
+                    float *row = reinterpret_cast<float *>(grad_rows) + kRowFloats * (size_t)slot_j;
+                    const int h = lane & 31;
+                    if (h == 0) {
+                        const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
+                        const float gx = 2.f * a.z * s[0] + a.w * s[1], gy = 2.f * b.x * s[1] + a.w * s[0];
+                        row[0] = gx * (0.69314718f * half_w); row[1] = gy * (0.69314718f * half_h); row[2] = s[2] * -0.5f;
+                        row_valid[slot_j] = 1;                  // (cleared ahead of the launch; rows nobody writes are never read)
+                    } else if (row_off >= 0) {
+                        float v = s[0] * row_mul;
+                        if (h == 16) {
+                            v = s[0] * __builtin_amdgcn_exp2f(-sh_rec[3 * j + 1].y);       // dL/dopacity = sum(ga dL/dalpha) / opacity
+                            row[7] = s[2];
+                        }
+                        row[row_off] = v;
+                    }
                 };
                 // The accepted splats are reduced over the wave TWO at a time: v_permlane32_swap exchanges the upper half
                 // of the first splat's sums with the lower half of the second's, one add folds the halves, and the five
                 // remaining DPP steps run once for both (7 instructions per quantity for two splats instead of 12).  The
                 // first splat's totals land in lane 31, the second's in lane 63; each stores its own row.
                 while (act != 0ull) {
-                    float s1[9], lop1 = 0.f;
+                    float s1[9];
                     int j1 = 0;
                     bool have1 = false;
                     while (act != 0ull && !have1) {
                         j1 = __ffsll((long long)act) - 1;
                         act &= act - 1ull;
-                        have1 = splat_pass(j1, s1, lop1);
+                        have1 = splat_pass(j1, s1);
                     }
                     if (!have1) break;
-                    float s2[9], lop2 = 0.f;
+                    float s2[9];
                     int j2 = 0;
                     bool have2 = false;
                     while (act != 0ull && !have2) {
                         j2 = __ffsll((long long)act) - 1;
                         act &= act - 1ull;
-                        have2 = splat_pass(j2, s2, lop2);
+                        have2 = splat_pass(j2, s2);
                     }
-                    if (have2) {
-                        wave_sum9_two(s1, s2);                                   // s1: splat j1 in lane 31, splat j2 in lane 63
-                        const uint32_t slot1 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j1);
-                        const uint32_t slot2 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j2);
-                        if ((lane & 31) == 31) store_row(s1, lane < 32 ? lop1 : lop2, lane < 32 ? slot1 : slot2);
-                    } else {
-                        wave_sum9_to_lane63(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7], s1[8]);
-                        const uint32_t slot1 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j1);
-                        if (lane == kWave - 1) store_row(s1, lop1, slot1);
+                    if (!have2) {                              // the batch's odd splat out: the second half of the tree runs on zeros
+#pragma unroll
+                        for (int i = 0; i < 9; ++i) s2[i] = 0.f;
                     }
+                    wave_sum9_two(s1, s2);                     // first splat's totals in lanes 0..31, second's in 32..63
+                    const uint32_t slot1 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j1);
+                    const uint32_t slot2 = (uint32_t)__builtin_amdgcn_readlane((int)slot, have2 ? j2 : j1);
+                    if (lane < 32 || have2) store_rows(s1, lane < 32 ? j1 : j2, lane < 32 ? slot1 : slot2);
                 }
             }
         }
