@@ -50,6 +50,18 @@ def _gc_cb(phase, info):                     # what the interpreter's cyclic col
 gc.callbacks.append(_gc_cb)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+_AFFINITY = {"original": None, "bound": None}      # the process's CPU mask at start / after the NUMA binding
+
+
+def _set_affinity_all_threads(cpus):
+    """Every thread of this process (the autograd engine's worker exists already) onto `cpus`."""
+    if not cpus:
+        return
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), cpus)
+        except OSError:
+            pass
 
 
 def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, C=3):
@@ -97,7 +109,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)   # 0.8 ms steps: a 20-step window (16 ms) measured the clock ramp, not the step
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg3n", "cfg3b", "cfg5"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg3n", "cfg3b", "cfg5", "cfg5n"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the non-saturating scene and the second seed")
     ap.add_argument("--no-extras", action="store_true", help="skip the comparison passes (torch getters, fused activations, ...) "
@@ -105,8 +117,10 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="rehearsal on one GPU: run the N > 1 code path (RCCL process group, ShardedRenderer, slab-local loss) "
                          "with world_size 1")
-    ap.add_argument("--train-loop", type=int, default=0, metavar="ITERS",
-                    help="also time ITERS iterations of the full training loop (Adam, densify every 100) on the workload")
+    ap.add_argument("--train-loop", type=int, default=300, metavar="ITERS",
+                    help="also time ITERS iterations of the full training loop (Adam, densify every 100) on the workload: BASELINE "
+                         "configs[2] taken literally (0 = skip)")
+    ap.add_argument("--no-4k", action="store_true", help="skip the 5M-Gaussian / 3840x2160 non-saturating stress (secondary_4k)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -123,9 +137,11 @@ def main():
     torch.cuda.set_device(local_rank % n_dev)
     dev = torch.device("cuda", local_rank % n_dev)
     bound = None
+    _AFFINITY["original"] = set(os.sched_getaffinity(0))
     if os.environ.get("GSR_BENCH_BIND", "1") != "0":
         from diff_gaussian_rasterization.hostbind import bind_to_gpu_numa_node
         bound = bind_to_gpu_numa_node(local_rank % n_dev, all_threads=os.environ.get("GSR_BENCH_BIND") == "all")
+        _AFFINITY["bound"] = set(os.sched_getaffinity(0)) if bound else None
     dist = None
     collectives = None
     if world > 1 or args.force_sharded:
@@ -167,7 +183,7 @@ def main():
         "host": {"bound_to_numa_node": bound[0] if bound else None, "cpus": len(os.sched_getaffinity(0))},
         "kernels": m["kernels"], "roofline": m["roofline"], "cpu_baseline": None,
     }
-    for k in ("native_getters", "torch_getters", "fused_activations", "getter_fusion", "reference_loss_composition"):
+    for k in ("native_getters", "torch_getters", "fused_activations", "getter_fusion", "reference_loss_composition", "unchanged_caller"):
         if m.get(k) is not None:
             line[k] = m[k]
     if single and not args.no_secondary and args.workload == "cfg3":
@@ -181,9 +197,22 @@ def main():
             "other_seed": {"what": "cfg3's generator, seed 33 instead of 3", "value": other["value"],
                            "ms_per_step": other["ms_per_step"], "config": other["config"]},
         }
-    if single and args.train_loop > 0:
+    if single and not args.no_4k and args.workload == "cfg3":
+        k4 = measure("cfg5n", max(args.steps // 8, 5), 3, ctx, extras=False, traffic=False)
+        stream = {k: {"ms_per_step": v["ms_per_step"], "alg_GBs": v["alg_GBs"], "hbm_frac": round((v["alg_GBs"] or 0.0) / HBM_PEAK_GBS, 4)}
+                  for k, v in k4["kernels"].items() if k in ("preprocess", "chunk_colors", "geom_bwd", "depth_hist", "depth_partition", "reduce_rows",
+                                                             "chunk_sort", "tile_sort", "emit", "ranges", "loss_fwd", "loss_bwd")}
+        line["secondary_4k"] = {
+            "what": "BASELINE configs[4]'s size (5M Gaussians, 3840x2160, SH 3) on ONE GPU with a generator that does not saturate "
+                    "(scene_synth.CONFIGS['cfg5n']: the cfg3n recipe): the streaming kernels at the size the config names; hbm_frac = "
+                    "algorithmic bytes / time / 8 TB/s per kernel; PMC traffic of the same run: profiles/r03_cfg5n_traffic.json",
+            "value": k4["value"], "unit": "images/s", "ms_per_step": k4["ms_per_step"], "steps": max(args.steps // 8, 5), "config": k4["config"],
+            "raster_ms_per_step": k4["raster_ms_per_step"], "kernels": k4["kernels"], "streaming": stream, "roofline": k4["roofline"],
+            "pmc_traffic": _profiles_json("r03_cfg5n_traffic.json")}
+    if single and args.train_loop > 0 and args.workload in ("cfg3", "cfg2", "cfg3n"):
         line["train_loop"] = _train_loop(args.workload, args.train_loop, dev, False)
-        line["train_loop"]["native_getters"] = _train_loop(args.workload, args.train_loop, dev, True)
+        if os.environ.get("GSR_BENCH_TRAIN_BOTH"):
+            line["train_loop"]["native_getters"] = _train_loop(args.workload, args.train_loop, dev, True)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = _cpu_baseline(args.workload)
     print(json.dumps(line))
@@ -328,6 +357,24 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
                         "the fused kernels; torch_ops_ms_per_step = the same composition in plain torch ops (5 depthwise "
                         "convolutions and their backward), what an import of the reference's own utils/loss_utils.py gives",
                 "torch_ops_ms_per_step": round(1e3 * el_torch / n_torch, 4)}
+    if extras:
+        # (6) ONE number for the truly unchanged caller (north_star: "consume it unchanged"): the reference's own parameter store
+        # (torch getters, scene/gaussian_model.py:101-125), its render() call sequence (gaussian_renderer/__init__.py:53-93), its
+        # two-call loss (train.py:104-105 over utils/loss_utils.py:17-63 signatures) — and no host placement: the NUMA binding of
+        # this process is undone for the leg (a caller who changes nothing does not bind either).
+        import loss_utils
+        active["m"] = store
+        loss_fn["f"] = lambda image, g: (1.0 - 0.2) * loss_utils.l1_loss(image, g) + 0.2 * (1.0 - loss_utils.ssim(image, g))
+        _set_affinity_all_threads(_AFFINITY["original"])
+        el, _ = timed(steps, max(warmup, 1))
+        _set_affinity_all_threads(_AFFINITY["bound"] or _AFFINITY["original"])
+        loss_fn["f"] = None
+        active["m"] = model
+        res["unchanged_caller"] = {
+            "value": round(steps / el, 3), "unit": "images/s", "ms_per_step": round(1e3 * el / steps, 4),
+            "what": "the reference's caller, nothing changed but the import: GaussianParams (torch exp / normalize / sigmoid / cat getters "
+                    "and their autograd backward) -> render() -> GaussianRasterizer.forward; loss = (1 - 0.2) * l1_loss(image, gt) + 0.2 * "
+                    "(1 - ssim(image, gt)) as two calls; the process NOT bound to the GPU's NUMA node"}
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if dist.get_backend() == "gloo" else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z, BwdUni
     unsigned block = blockIdx.x, blocks = gridDim.x;
     if constexpr (UNITS) {
         if (blockIdx.x == 0) {
-            bwd_units_block<kGeomBlock>(ua);
+            bwd_units_block<kGeomBlock, 16>(ua);
             return;
         }
         block -= 1; blocks -= 1;

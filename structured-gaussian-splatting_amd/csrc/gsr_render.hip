@@ -458,7 +458,7 @@ __device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &s
 
 // The unit list (gsr_bwd_units.h) in its own launch: only when the forward's zero fill did not carry it (k_zero_segments<true>,
 // gsr_geom.hip).
-__global__ __launch_bounds__(1024) void k_bwd_units(BwdUnitArgs a) { bwd_units_block<1024>(a); }
+__global__ __launch_bounds__(1024) void k_bwd_units(BwdUnitArgs a) { bwd_units_block<1024, 8>(a); }
 
 BwdUnitArgs bwd_unit_args(const FrameK &f, int chunks_run, const BinningWS &bw, const ImageWS &iw)
 {

@@ -14,14 +14,25 @@ def bind_to_gpu_numa_node(index: int = 0, all_threads: bool = False):
     CPUs) or None when sysfs does not say."""
     try:
         import glob
-        bus = int(torch.cuda.get_device_properties(index).pci_bus_id)
+        props = torch.cuda.get_device_properties(index)
+        want = (int(getattr(props, "pci_domain_id", 0)), int(props.pci_bus_id), int(getattr(props, "pci_device_id", 0)))
     except Exception:
         return None
+    # match domain, bus and device together: on multi-domain hosts two cards can share a bus number, and the wrong socket's CPUs
+    # are exactly what this helper exists to avoid; more than one match -> do nothing
+    found = []
     for d in glob.glob("/sys/class/drm/card*/device"):
         try:
             bdf = os.path.basename(os.readlink(d))                    # 0000:d9:00.0
-            if int(bdf.split(":")[1], 16) != bus:
-                continue
+            dom, bus, rest = bdf.split(":")
+            if (int(dom, 16), int(bus, 16), int(rest.split(".")[0], 16)) == want:
+                found.append(d)
+        except (OSError, ValueError, IndexError):         # a card without a PCI address
+            continue
+    if len({os.path.realpath(d) for d in found}) != 1:
+        return None
+    for d in found[:1]:
+        try:
             node = int(open(os.path.join(d, "numa_node")).read())
             if node < 0:
                 return None

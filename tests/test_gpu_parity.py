@@ -622,7 +622,7 @@ def test_cfg2_full_size_vs_oracle():
     assert live > 1000
 
 
-@pytest.mark.parametrize("workload", ["cfg3", "cfg5"])
+@pytest.mark.parametrize("workload", ["cfg3", "cfg5", "cfg5n"])
 def test_full_size_properties(workload):
     """BASELINE.json configs[2] (1M Gaussians, 1920x1080) and configs[4] (5M Gaussians, 3840x2160 — the maximum size,
     on ONE GPU) through size-independent properties: determinism, linearity of the backward in dL/dcolor, bg linearity
