@@ -149,6 +149,9 @@ static int validate_inputs(const gsr_frame_desc *d, const gsr_camera *c, const g
 // the copy is a 5 us kernel of its own and the event another packet, both on the critical path of a 0.8 ms step.)  A frame
 // whose geometry workspace is absent, or a stream that drains without the word arriving, falls back to the copy.
 constexpr double kReadbackTimeoutS = 30.0;
+// experiment switches (tools/): read ONCE, when the library is loaded — a re-run of gsr_forward_render after GSR_ERR_WORKSPACE must
+// take the decisions of the first run, whatever the environment does in between
+static const bool kNoLiveFilter = getenv("GSR_NO_LIVE_FILTER") != nullptr, kNoChunkMerge = getenv("GSR_NO_CHUNK_MERGE") != nullptr;
 
 static inline void cpu_pause()
 {
@@ -396,7 +399,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         LiveParts parts{1, {0}, {0}};
         const long long slab_tiles_now = (long long)(f.ty1 - f.ty0) * f.Gx;
         if (c > 0 && c >= plan->chunks_sorted && c < plan->num_chunks - 1 && stuck_now > 0 && (long long)open_now * 2 < slab_tiles_now &&
-            !getenv("GSR_NO_LIVE_FILTER") && !getenv("GSR_NO_CHUNK_MERGE")) {
+            !kNoLiveFilter && !kNoChunkMerge) {
             const int last_c = plan->num_chunks - 1;
             uint64_t m_max = 0;
             for (int j = c; j <= last_c; ++j) m_max += (uint64_t)plan->chunk_instances_max[j];
@@ -435,7 +438,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         // (launch_live_filter) — only those get sorted and binned, one wave each.
         const uint64_t chunk_n = (uint64_t)(r1 - r0), chunk_max = (uint64_t)plan->chunk_instances_max[c];
         const bool filtered = c > 0 && r1 - r0 >= kLiveFilterMin && (long long)open_now * 2 < (long long)(f.ty1 - f.ty0) * f.Gx &&
-                              chunk_max / 32 + 2 * chunk_n + 4 <= chunk_max && !getenv("GSR_NO_LIVE_FILTER");
+                              chunk_max / 32 + 2 * chunk_n + 4 <= chunk_max && !kNoLiveFilter;
         if (filtered) plan->chunks_filtered |= 1 << c;
         if (c >= plan->chunks_sorted) {
             if (filtered && (rc = launch_live_filter(f, c, r0, r1, parts, gw, iw, dbg, s))) return rc;
@@ -619,7 +622,7 @@ int gsr_exchange_rows_scatter(const gsr_frame_desc *desc, int32_t n_rows, const 
     int rc = validate(desc);
     if (rc) return rc;
     if (n_rows < 0 || (n_rows > 0 && (!rows || !packed || !screen_grads))) { set_error("gsr_exchange_rows_scatter: bad argument"); return GSR_ERR_INVALID_ARGUMENT; }
-    return launch_rows_scatter(n_rows, rows, packed, screen_grads, desc->debug != 0, (hipStream_t)stream);
+    return launch_rows_scatter(n_rows, desc->P, rows, packed, screen_grads, desc->debug != 0, (hipStream_t)stream);
 }
 
 int gsr_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

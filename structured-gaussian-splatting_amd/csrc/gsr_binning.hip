@@ -865,7 +865,8 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     // scratch (mask prefixes, rank metadata: n_max / 64 + 9 n + 4 words) sits in the other idle key buffer
     const uint64_t slab_tiles = (uint64_t)(f.ty1 - f.ty0) * (uint64_t)f.Gx;
     const uint64_t scratch_words = n_max / 64 + 1 + 9 * (uint64_t)n + 4;
-    const bool gather = !flat && !filtered && !getenv("GSR_NO_GATHER") && n < (1 << 26) && (uint64_t)n * slab_tiles <= 24 * n_max + (1ull << 22) &&
+    static const bool no_gather = getenv("GSR_NO_GATHER") != nullptr;      // experiment switch, read once
+    const bool gather = !flat && !filtered && !no_gather && n < (1 << 26) && (uint64_t)n * slab_tiles <= 24 * n_max + (1ull << 22) &&
                         scratch_words <= n_max;
     uint32_t *scratch = bw.keys[0] + ((emitted_before + 3) & ~(uint64_t)3);
     uint4 *meta_a = reinterpret_cast<uint4 *>(scratch);

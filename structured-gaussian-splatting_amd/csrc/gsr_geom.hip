@@ -488,6 +488,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
     const int r = blockIdx.x * kGeomBlock + threadIdx.x;
     if (r >= n_ranks) return;
     const int i = (int)order[r];
+    if (i < 0 || i >= f.P) return;               // (an exchange list entry nobody filled: -1)
     if (radii[i] <= 0) return;
     const float4 s0 = screen[3 * (size_t)i], s1 = screen[3 * (size_t)i + 1], s2 = screen[3 * (size_t)i + 2];
     const bool live = (s0.x != 0.f) | (s0.y != 0.f) | (s0.z != 0.f) | (s0.w != 0.f) | (s1.x != 0.f) | (s1.y != 0.f) |

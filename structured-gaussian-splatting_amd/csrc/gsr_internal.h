@@ -198,7 +198,7 @@ int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussian
 int launch_depth_select(const FrameK &f, GeomWS &ws, bool debug, hipStream_t s, void *clear16 = nullptr, size_t clear16_n = 0);
 int launch_rows_gather(const FrameK &f, GeomWS &ws, uint32_t key_max, const float *screen, int n_rows, int32_t *rows, float *packed,
                        bool debug, hipStream_t s);
-int launch_rows_scatter(int n_rows, const int32_t *rows, const float *packed, float *screen, bool debug, hipStream_t s);
+int launch_rows_scatter(int n_rows, int P, const int32_t *rows, const float *packed, float *screen, bool debug, hipStream_t s);
 int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_t key_hi, bool first, GeomWS &ws, bool debug, hipStream_t s,
                        const uint32_t *live_count = nullptr);
 // parts: the range may span several planned chunks (merged by the caller); their relative keys are re-based to the first one's

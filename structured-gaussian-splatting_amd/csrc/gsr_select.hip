@@ -441,11 +441,13 @@ __global__ __launch_bounds__(kRowsThreads) void k_rows_gather(int P, const uint3
     }
 }
 
-__global__ __launch_bounds__(256) void k_rows_scatter(int n_rows, const int32_t *__restrict__ rows, const float4 *__restrict__ packed,
+__global__ __launch_bounds__(256) void k_rows_scatter(int n_rows, int P, const int32_t *__restrict__ rows, const float4 *__restrict__ packed,
                                                       float4 *__restrict__ screen)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n_rows) return;
+    // (entries the gather did not fill stay -1: ranks that disagree on the depth keys must not write out of range)
+    if (rows[r] < 0 || rows[r] >= P) return;
     const size_t i = (size_t)rows[r];
     screen[3 * i] = packed[3 * (size_t)r]; screen[3 * i + 1] = packed[3 * (size_t)r + 1]; screen[3 * i + 2] = packed[3 * (size_t)r + 2];
 }
@@ -465,11 +467,11 @@ int launch_rows_gather(const FrameK &f, GeomWS &ws, uint32_t key_max, const floa
     return GSR_OK;
 }
 
-int launch_rows_scatter(int n_rows, const int32_t *rows, const float *packed, float *screen, bool debug, hipStream_t s)
+int launch_rows_scatter(int n_rows, int P, const int32_t *rows, const float *packed, float *screen, bool debug, hipStream_t s)
 {
     if (n_rows <= 0) return GSR_OK;
     ProfileScope prof("exchange_rows", s);
-    hipLaunchKernelGGL(k_rows_scatter, dim3((n_rows + 255) / 256), dim3(256), 0, s, n_rows, rows, reinterpret_cast<const float4 *>(packed),
+    hipLaunchKernelGGL(k_rows_scatter, dim3((n_rows + 255) / 256), dim3(256), 0, s, n_rows, P, rows, reinterpret_cast<const float4 *>(packed),
                        reinterpret_cast<float4 *>(screen));
     GSR_LAUNCH_CHECK("exchange_rows(scatter)", debug, s);
     return GSR_OK;
@@ -728,7 +730,7 @@ int launch_chunk_order(const FrameK &f, int r0, int r1, uint32_t key_lo, uint32_
     int bits = bits_of(key_hi > base ? key_hi - base : 0u);
     if (bits < 1) bits = 1;
     if (n <= kSmallSortMax && !live_count) {
-        const int force_radix = getenv("GSR_SORT_FORCE_RADIX") ? 1 : 0;               // test hook: the fallback path of the LDS sort
+        const int force_radix = getenv("GSR_SORT_FORCE_RADIX") ? 1 : 0;               // test hook (tests set it per case): the fallback path of the LDS sort
         ProfileScope prof("chunk_sort", s);
         if (n <= kSmallSortMax / 2)
             hipLaunchKernelGGL(k_chunk_sort_small<kSmallSortMax / 2>, dim3(1), dim3(kSmallThreads), 0, s, n, (uint32_t)r0, bits, force_radix,

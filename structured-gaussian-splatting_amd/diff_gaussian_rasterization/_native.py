@@ -235,8 +235,10 @@ def frame_arrays(desc, geom_ws):
 def exchange_rows_gather(desc, geom_ws, key_max: int, screen, n_rows: int):
     """(rows int32 [n_rows], packed float32 [n_rows, 12]): the Gaussians with depth key <= key_max in index order and their
     screen-gradient rows, packed for one all-reduce."""
-    rows = torch.empty(n_rows, dtype=torch.int32, device=screen.device)
-    packed = torch.empty(n_rows, SCREEN_GRAD_STRIDE, dtype=torch.float32, device=screen.device)
+    # n_rows comes from ANOTHER rank's count: entries this rank's keys do not fill must be inert (-1 is skipped by the scatter and by
+    # the sparse geometry backward; their packed rows are zero), not whatever the allocator left there
+    rows = torch.full((n_rows,), -1, dtype=torch.int32, device=screen.device)
+    packed = torch.zeros(n_rows, SCREEN_GRAD_STRIDE, dtype=torch.float32, device=screen.device)
     _check(load().gsr_exchange_rows_gather(C.byref(desc), _ptr(geom_ws), C.c_uint32(int(key_max) & 0xFFFFFFFF), _ptr(screen), C.c_int32(n_rows),
                                            _ptr(rows), _ptr(packed), _stream(screen.device)), "gsr_exchange_rows_gather")
     return rows, packed

@@ -134,8 +134,9 @@ class NativeBackend:
 class _Comm:
     """The three collectives of the path, with a gloo-compatible form for the CPU tests."""
 
-    def __init__(self, dist, world, rank, group=None):
+    def __init__(self, dist, world, rank, group=None, async_gather=True):
         self.dist, self.world, self.rank, self.group = dist, world, rank, group
+        self.async_gather = async_gather                   # False: the plain blocking all_gather (A/B switch, see ShardedRenderer)
         self.gloo = dist.get_backend(group) == "gloo"      # tests only: device tensors are staged through the host
         self.native_rs = not self.gloo
         self._pinned, self._pinned_turn = {}, 0
@@ -152,7 +153,7 @@ class _Comm:
     def all_gather_begin(self, shard: torch.Tensor):
         """all_gather in two halves: the collective is started here (on RCCL's own stream), the returned callable makes the
         current stream wait for it and hands out the result — what the caller enqueues in between runs beside the transfer."""
-        if self.gloo or shard.device.type == "cpu":
+        if self.gloo or shard.device.type == "cpu" or not self.async_gather:
             out = self.all_gather(shard)
             return lambda: out
         out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
@@ -372,13 +373,16 @@ class ShardedRenderer:
     gaussian_renderer.render, reference gaussian_renderer/__init__.py:18-100)."""
 
     def __init__(self, dist, world: int, rank: int, backend=None, group=None, row_weights=None,
-                 backward_mode: str = "allreduce_screen", balance_every: int = 0):
+                 backward_mode: str = "allreduce_screen", balance_every: int = 0, async_gather: bool = True):
         """row_weights: fixed per-tile-row weights for the slab boundaries (None = equal rows).  balance_every = k > 0:
         SURVEY 7 "slab load balance" — every k-th frame the ranks' measured per-tile-row work (instances binned) rides
-        on the all-gather and the next frames' slabs are cut at equal cumulative work."""
+        on the all-gather and the next frames' slabs are cut at equal cumulative work.  async_gather=False: the slabs'
+        all-gather as one blocking collective instead of async_op + a stream-level wait with the backward's zero fill enqueued in
+        between — the asynchronous form has only ever run at world size 1 on real RCCL (no multi-GPU lease so far): the switch
+        lets a 2-GPU run A/B the two (tests/test_gpu_sharded.py::test_two_rank_rccl_equals_single_render does)."""
         assert backward_mode in ("allreduce_screen", "reduce_scatter")
         self.balance_every, self._frames, self._pending = int(balance_every), 0, None
-        self.comm = _Comm(dist, world, rank, group)
+        self.comm = _Comm(dist, world, rank, group, async_gather=async_gather)
         self.backend = NativeBackend() if backend is None else backend
         self.row_weights = row_weights
         self.backward_mode = backward_mode

@@ -321,9 +321,63 @@ class GaussianModel:
         self.prune_points(drop)
 
     # ---- persistence -----------------------------------------------------------------------------------------
+    # The checkpoint tuple is the reference's (scene/gaussian_model.py:67-99, saved by train.py as chkpnt*.pth), its optimizer
+    # state_dict included: six groups with one tensor each (params 0..5 = xyz, f_dc, f_rest, opacity, scaling, rotation), every
+    # group carrying torch.optim.Adam's own keys.  In memory f_dc and f_rest share one table; the two layouts are converted here,
+    # at the boundary, so that checkpoints move both ways between this class and the reference's.
+    def _optimizer_state_reference_layout(self):
+        sd = self.optimizer.state_dict()
+        defaults = {k: v for k, v in torch.optim.Adam([torch.zeros(1)], lr=0.0, eps=1e-15).param_groups[0].items() if k != "params"}
+        groups, state, new_id = [], {}, 0
+        for g in sd["param_groups"]:
+            hyper = {**defaults, **{k: v for k, v in g.items() if k not in ("params", "head_cols", "tail")}}
+            if g.get("name") == "f_rest":
+                continue                                         # emitted together with "f_dc" below
+            st = sd["state"].get(g["params"][0]) if g["params"] else None
+            if g.get("name") == "f_dc":
+                rest = next(x for x in sd["param_groups"] if x.get("name") == "f_rest")
+                for hyp, cols in ((hyper, slice(0, 1)), ({**defaults, **{k: v for k, v in rest.items() if k != "params"}}, slice(1, None))):
+                    groups.append({**hyp, "params": [new_id]})
+                    if st is not None:
+                        state[new_id] = {"step": st["step"].clone(), "exp_avg": st["exp_avg"][:, cols].contiguous(),      # (two tensors: own counters)
+                                         "exp_avg_sq": st["exp_avg_sq"][:, cols].contiguous()}
+                    new_id += 1
+                continue
+            groups.append({**hyper, "params": [new_id]})
+            if st is not None:
+                state[new_id] = st
+            new_id += 1
+        return {"state": state, "param_groups": groups}
+
+    def _load_optimizer_state(self, sd):
+        """Accepts the reference's six-tensor layout (what capture() emits, what the reference's own checkpoints hold) and this
+        class's packed one (five tensors; checkpoints written by earlier versions of this package)."""
+        groups = sd["param_groups"]
+        mine = self.optimizer.state_dict()["param_groups"]
+        if len(groups) == 6 and all(len(g["params"]) == 1 for g in groups):
+            by_name = {g.get("name", GROUPS[i]): g for i, g in enumerate(groups)}
+            state, new_groups = {}, []
+            for tmpl in mine:
+                src = by_name[tmpl["name"]]
+                new_groups.append({**{k: v for k, v in src.items() if k != "params"}, **{k: tmpl[k] for k in ("head_cols", "tail") if k in tmpl},
+                                   "params": list(tmpl["params"])})
+                if not tmpl["params"]:
+                    continue
+                if tmpl["name"] == "f_dc":
+                    dc, rest = sd["state"].get(by_name["f_dc"]["params"][0]), sd["state"].get(by_name["f_rest"]["params"][0])
+                    if dc is not None:
+                        cat = lambda k: dc[k] if rest is None or rest[k].numel() == 0 else torch.cat((dc[k], rest[k]), dim=1)
+                        state[tmpl["params"][0]] = {"step": dc["step"], "exp_avg": cat("exp_avg"), "exp_avg_sq": cat("exp_avg_sq")}
+                else:
+                    st = sd["state"].get(src["params"][0])
+                    if st is not None:
+                        state[tmpl["params"][0]] = st
+            sd = {"state": state, "param_groups": new_groups}
+        self.optimizer.load_state_dict(sd)
+
     def capture(self):
         return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,
-                self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self.optimizer.state_dict(),
+                self._opacity, self.max_radii2D, self.xyz_gradient_accum, self.denom, self._optimizer_state_reference_layout(),
                 self.spatial_lr_scale)
 
     def restore(self, model_args, training_args):
@@ -333,7 +387,7 @@ class GaussianModel:
         self.max_radii2D = max_radii
         self.training_setup(training_args)
         self.xyz_gradient_accum, self.denom = accum, denom
-        self.optimizer.load_state_dict(opt_state)
+        self._load_optimizer_state(opt_state)
 
     def save_ply(self, path):
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)

@@ -134,9 +134,10 @@ def _rccl_worker(rank, world, port, q):
         bg = torch.tensor([0.2, 0.1, 0.3], device=dev)
         gt = torch.rand(3, 304, 400, generator=torch.Generator().manual_seed(77)).to(dev)
         res = {}
-        for mode in ("allreduce_screen", "reduce_scatter", "loss"):
+        for mode in ("allreduce_screen", "reduce_scatter", "loss", "allreduce_screen/sync_gather"):
             model = GaussianParams(scene.to(dev)).to(dev)
-            sr = ShardedRenderer(dist, world, rank, backward_mode="allreduce_screen" if mode == "loss" else mode)
+            sr = ShardedRenderer(dist, world, rank, backward_mode="reduce_scatter" if mode == "reduce_scatter" else "allreduce_screen",
+                                 async_gather=not mode.endswith("sync_gather"))          # A/B of the asynchronous all-gather (unverified at world > 1)
             out = sr.render(cam, model, Pipe(), bg)
             if mode == "loss":
                 sr.training_loss(out["render"], gt).backward()
@@ -168,8 +169,8 @@ def test_two_rank_rccl_equals_single_render():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for mode in ("allreduce_screen", "reduce_scatter", "loss"):
-        want = _render(0, 1, mode)
+    for mode in ("allreduce_screen", "reduce_scatter", "loss", "allreduce_screen/sync_gather"):
+        want = _render(0, 1, mode.split("/")[0])
         want.pop("loss", None)
         _assert_equal_single({r: results[r][mode] for r in range(world)}, want, world)
 

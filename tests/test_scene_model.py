@@ -98,6 +98,60 @@ def test_structural_edits_keep_adam_state_aligned():
     assert torch.equal(gm3._xyz.detach(), gm._xyz.detach()) and gm3.active_sh_degree == gm.active_sh_degree
 
 
+def _reference_style_adam(tensors):
+    """torch.optim.Adam built the way the reference's training_setup builds it (scene/gaussian_model.py:159-177)."""
+    names = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+    return torch.optim.Adam([{"params": [tensors[n]], "lr": 1e-3 * (i + 1), "name": n} for i, n in enumerate(names)], lr=0.0, eps=1e-15)
+
+
+def test_checkpoint_optimizer_state_is_the_reference_layout_both_ways():
+    """capture() emits the reference's six-tensor Adam state_dict (chkpnt*.pth of train.py), restore() reads it: a state saved by a
+    torch.optim.Adam built the reference way loads into this class, and this class's captured state loads into such an optimizer."""
+    torch.manual_seed(3)
+    gm = _model(200)
+    for g in gm.optimizer.param_groups:
+        for p in g["params"]:
+            p.grad = torch.randn_like(p)
+    gm.optimizer.step()
+    snap = gm.capture()
+    sd = snap[10]
+    assert [g["name"] for g in sd["param_groups"]] == ["xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    assert [g["params"] for g in sd["param_groups"]] == [[0], [1], [2], [3], [4], [5]]
+    assert sd["state"][1]["exp_avg"].shape == (200, 1, 3) and sd["state"][2]["exp_avg"].shape == (200, 15, 3)
+    # (a) this class's captured state -> an optimizer built the reference way
+    ref_t = {n: torch.nn.Parameter(t.detach().clone()) for n, t in (("xyz", gm._xyz), ("f_dc", gm._features_dc.contiguous()),
+             ("f_rest", gm._features_rest.contiguous()), ("opacity", gm._opacity), ("scaling", gm._scaling), ("rotation", gm._rotation))}
+    ref = _reference_style_adam(ref_t)
+    ref.load_state_dict(sd)
+    feats = gm.optimizer.state[gm._features]
+    assert torch.equal(ref.state[ref_t["f_dc"]]["exp_avg"], feats["exp_avg"][:, :1])
+    assert torch.equal(ref.state[ref_t["f_rest"]]["exp_avg_sq"], feats["exp_avg_sq"][:, 1:])
+    assert torch.equal(ref.state[ref_t["rotation"]]["exp_avg"], gm.optimizer.state[gm._rotation]["exp_avg"])
+    for p in ref_t.values():                                  # and it steps (every Adam key is there)
+        p.grad = torch.randn_like(p)
+    ref.step()
+    # (b) a state_dict written by the reference-style optimizer -> this class
+    ref.param_groups[2]["lr"], ref.param_groups[5]["lr"] = 3e-3, 6e-3
+    snap_ref = snap[:10] + (ref.state_dict(),) + snap[11:]
+    gm2 = GaussianModel(3)
+    gm2.restore(snap_ref, OptimizationDefaults())
+    f2 = gm2.optimizer.state[gm2._features]
+    assert torch.equal(f2["exp_avg"][:, :1], ref.state[ref_t["f_dc"]]["exp_avg"])
+    assert torch.equal(f2["exp_avg_sq"][:, 1:], ref.state[ref_t["f_rest"]]["exp_avg_sq"])
+    assert float(f2["step"]) == float(ref.state[ref_t["f_dc"]]["step"]) == 2.0
+    assert torch.equal(gm2.optimizer.state[gm2._opacity]["exp_avg"], ref.state[ref_t["opacity"]]["exp_avg"])
+    lrs = {g["name"]: g["lr"] for g in gm2.optimizer.param_groups}
+    assert lrs["f_rest"] == 3e-3 and lrs["rotation"] == 6e-3      # hyper-parameters come from the loaded state, as torch's do
+    for g in gm2.optimizer.param_groups:                      # and the restored model keeps stepping
+        for p in g["params"]:
+            p.grad = torch.randn_like(p)
+    gm2.optimizer.step()
+    # (c) the packed layout of earlier versions of this package still loads
+    gm3 = GaussianModel(3)
+    gm3.restore(snap[:10] + (gm.optimizer.state_dict(),) + snap[11:], OptimizationDefaults())
+    assert torch.equal(gm3.optimizer.state[gm3._features]["exp_avg"], feats["exp_avg"])
+
+
 def test_packed_features_behave_as_the_reference_two_tensors():
     """get_features is the interleaved table itself (= torch.cat of its two column ranges, scene/gaussian_model.py:118-121);
     _features_dc / _features_rest are views with the reference's shapes, and gradients through either reach the table."""
