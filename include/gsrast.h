@@ -84,8 +84,8 @@ typedef struct gsr_frame_plan {
                                                      gsr_forward_render (after GSR_ERR_WORKSPACE) does not sort them again   */
     int32_t chunks_filtered;                      /* bit c: chunk c was put through the live filter (only the Gaussians that can still
                                                      reach an open tile sit at the front of its range, sorted and binned)        */
-    int32_t tile_order_ready;                     /* set by gsr_forward when its zero fill also built the blend backward's list of
-                                                     work units (gsr_backward_render then skips that launch); cleared by
+    int32_t tile_order_ready;                     /* set by gsr_forward when its zero fill also cleared the blend backward's row-valid
+                                                     flags (gsr_backward_render then skips that memset); cleared by
                                                      gsr_forward_render                                                         */
     int32_t reserved_;
 } gsr_frame_plan;
@@ -202,10 +202,14 @@ int gsr_bwd_segment_entries(void);
  * binned_ranks: a HINT — the number of leading depth ranks outside which `screen_grads` is known to be all
  * zero (plan->chunk_rank_begin[plan->chunks_run] for gradients that come from THIS frame's
  * gsr_backward_render, or the maximum over ranks after a multi-GPU sum), or -1 for "unknown".  When the whole
- * range is requested and the prefix is short the outputs are memset and only the prefix is visited. */
+ * range is requested and the prefix is short the outputs are memset and only the prefix is visited.
+ * own_plan (may be NULL): the frame's plan, when screen_grads come from gsr_backward_render of this very frame (and only then):
+ * replaces the hint — a rank that emitted no instance is skipped before anything of it is read, and a chunk that went through the
+ * live filter counts as nothing when choosing between "memset + visit" and the dense pass (a training frame whose last chunk is
+ * most of the scene binned a few per cent of it). */
 int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g,
                       const int32_t *radii, const void *geom_ws, const float *screen_grads, int32_t g_begin,
-                      int32_t g_end, int32_t binned_ranks, const gsr_grads *out, void *stream);
+                      int32_t g_end, int32_t binned_ranks, const gsr_frame_plan *own_plan, const gsr_grads *out, void *stream);
 
 /* gsr_backward_geom for an explicit list of Gaussians: the sparse geometry backward visits rows[0 .. n_rows) (device,
  * Gaussian indices) instead of the frame's own binned depth prefix; every other row of the outputs must already be zero
@@ -253,10 +257,11 @@ typedef struct gsr_debug_views {
     const int32_t *n_contrib;      /* [H*W] encoded: (chunk + 1) << 26 | position in that chunk's range  */
     const uint32_t *tile_walk;     /* [GSR_MAX_CHUNKS, Tn] entries of chunk c's range the blend backward walks on a tile (its deepest
                                       contributor there); defined where ranges[c][tile] is not empty      */
-    const uint32_t *bwd_units;     /* [*bwd_unit_count, 2] valid after gsr_backward_render (or a gsr_forward with early_fill): the blend
-                                      backward's work units, longest first: (tile | chunk << 24, segment | last-of-its-pair << 31) */
-    const uint32_t *bwd_unit_count; /* [1] */
-    uint64_t bwd_unit_capacity;
+    const uint32_t *bwd_units;     /* the blend backward's work units (tile | chunk << 24, segment), appended by the forward's waves as they
+                                      finish: per shard (= tile % 8) 17 lists, laid out [8][cap_full + 16 cap_part][2]: full segments, then
+                                      the pairs' partial last segments in 16 length classes, longest first */
+    const uint32_t *bwd_unit_count; /* [8, 17] units per shard and list */
+    uint32_t bwd_unit_cap_full, bwd_unit_cap_part;
 } gsr_debug_views;
 int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const void *binning_ws,
                         const void *image_ws, const gsr_frame_plan *plan_host, gsr_debug_views *views);

@@ -486,15 +486,13 @@ int gsr_forward(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gau
     if (plan->binning_capacity <= 0) plan->binning_capacity = 0;
     if ((rc = gsr_forward_render(desc, cam, g, geom_ws, binning_ws, image_ws, plan, out_color, stream))) return rc;
     if (early_fill && !early_fill->prezeroed && desc->P > 0 && plan->num_rendered > 0 && plan->chunks_run > 0 &&
-        (long long)plan->chunk_rank_begin[plan->chunks_run] * 4 < (long long)desc->P) {
+        effective_binned_ranks(*plan) * 4 < (long long)desc->P) {
         const FrameK f = make_frame(*desc);
-        const ImageWS iw = carve_image(image_ws, f);
         const BinningWS bw = carve_binning(binning_ws, plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered, f);
-        const BwdUnitArgs ua = bwd_unit_args(f, plan->chunks_run, bw, iw);
         ProfileScope prof("zero_outputs", (hipStream_t)stream);
-        if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream, &ua, bw.row_valid, valid_bytes(plan)))) return rc;
+        if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream, bw.row_valid, valid_bytes(plan)))) return rc;
         early_fill->prezeroed = 1;
-        plan->tile_order_ready = 1;                      // the fill carried the blend backward's unit list and cleared its row flags
+        plan->tile_order_ready = 1;                      // the fill also cleared the blend backward's row flags
     }
     return GSR_OK;
 }
@@ -549,18 +547,17 @@ int gsr_backward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const
     if (plan->num_rendered > 0) {
         if (!plan->tile_order_ready) GSR_HIP_CHECK(hipMemsetAsync(bw.row_valid, 0, valid_bytes(plan), s));
         if ((rc = launch_render_bwd(f, plan->chunks_run, plan->sort_result, plan->instances_emitted >= 0 ? (long long)plan->instances_emitted : rows_upper,
-                                    gw, bw, iw, out_color, dL_dcolor, dbg, s, plan->tile_order_ready != 0)))
+                                    gw, bw, iw, out_color, dL_dcolor, dbg, s)))
             return rc;
     }
     // only the depth ranks of chunks that ran can own gradient rows
-    const int n_ranks = (plan->num_rendered > 0 && plan->chunks_run > 0) ? plan->chunk_rank_begin[plan->chunks_run] : 0;
-    if ((rc = launch_reduce_rows(f, n_ranks, rows_upper, gw, bw, screen_grads, plan->screen_prezeroed, dbg, s))) return rc;
+    if ((rc = launch_reduce_rows(f, *plan, gw, bw, screen_grads, plan->screen_prezeroed, dbg, s))) return rc;
     return GSR_OK;
 }
 
 int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, const int32_t *radii,
                       const void *geom_ws, const float *screen_grads, int32_t g_begin, int32_t g_end, int32_t binned_ranks,
-                      const gsr_grads *out, void *stream)
+                      const gsr_frame_plan *own_plan, const gsr_grads *out, void *stream)
 {
     int rc = validate(desc);
     if (rc) return rc;
@@ -571,8 +568,15 @@ int gsr_backward_geom(const gsr_frame_desc *desc, const gsr_camera *cam, const g
     if (!radii || !geom_ws || !screen_grads) { set_error("gsr_backward_geom: NULL argument"); return GSR_ERR_INVALID_ARGUMENT; }
     const FrameK f = make_frame(*desc);
     GeomWS gw = carve_geom(const_cast<void *>(geom_ws), f.P);
+    // own_plan: the gradients come from gsr_backward_render of THIS frame: the ranks of the chunks that ran, and among them only
+    // those that emitted an instance, can be non-zero; sparse (fill + visit those) unless unfiltered chunks hold P / 4 Gaussians or more
+    bool own_sparse = false;
+    if (own_plan && g_begin == 0 && g_end == desc->P && own_plan->num_rendered > 0 && own_plan->chunks_run > 0) {
+        binned_ranks = own_plan->chunk_rank_begin[own_plan->chunks_run];
+        own_sparse = effective_binned_ranks(*own_plan) * 4 < (long long)desc->P;
+    }
     return launch_geom_bwd(f, *cam, *g, radii, gw, screen_grads, g_begin, g_end, binned_ranks, *out, desc->debug != 0,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, nullptr, own_sparse);
 }
 
 int gsr_backward_geom_rows(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, const int32_t *radii,
@@ -701,13 +705,13 @@ int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const v
     if (binning_ws) {
         BinningWS bw = carve_binning(const_cast<void *>(binning_ws), plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered, f);
         v->sorted_gaussian = bw.sorted_gid;
-        v->bwd_units = reinterpret_cast<const uint32_t *>(bw.units); v->bwd_unit_count = bw.n_units; v->bwd_unit_capacity = bw.unit_capacity;
+        v->bwd_units = reinterpret_cast<const uint32_t *>(bw.units.units); v->bwd_unit_cap_full = bw.units.cap_full; v->bwd_unit_cap_part = bw.units.cap_part;
     }
     if (image_ws) {
         ImageWS iw = carve_image(const_cast<void *>(image_ws), f);
         v->ranges = reinterpret_cast<const uint32_t *>(iw.ranges);
         v->final_T = iw.T_state; v->n_contrib = iw.last_enc;
-        v->tile_walk = iw.tile_walk;
+        v->tile_walk = iw.tile_walk; v->bwd_unit_count = iw.unit_count;
     }
     return GSR_OK;
 }

@@ -75,6 +75,7 @@ ImageWS carve_image(void *base, const FrameK &f)
     w.last_enc = (int32_t *)(b + o); o += align_up((N ? N : 1) * 4);
     w.ranges = (uint2 *)(b + o); o += align_up((Tn ? Tn : 1) * 8 * GSR_MAX_CHUNKS);
     w.tile_cnt = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);      // directly behind the ranges: one memset clears both
+    w.unit_count = (uint32_t *)(b + o); o += align_up(kUnitShards * kUnitClasses * 4);      // ... and these
     w.open = (uint32_t *)(b + o); o += align_up((Tn ? Tn : 1) * 4);
     w.open_bits = (unsigned long long *)(b + o); o += align_up((size_t)(f.Gy > 0 ? f.Gy : 1) * (size_t)((f.Gx + 63) / 64 + 1) * 8);
     w.ctrl_scratch = (Ctrl *)(b + o); o += align_up(sizeof(Ctrl));
@@ -96,9 +97,12 @@ BinningWS carve_binning(void *base, int64_t R, const FrameK &f)
     w.sorted_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
     w.row_valid = (uint8_t *)(b + o); o += align_up(Rn);
     w.ckpt = (float *)(b + o); o += align_up((Rn / kSeg + 2) * (size_t)kCkptFloats * sizeof(float));
-    w.unit_capacity = Rn / kSeg + (size_t)GSR_MAX_CHUNKS * Tn + 1;
-    w.units = (uint2 *)(b + o); o += align_up(w.unit_capacity * sizeof(uint2));
-    w.n_units = (uint32_t *)(b + o); o += align_up(16);
+    {
+        const size_t cf = Rn / kSeg + 1, cp = (size_t)GSR_MAX_CHUNKS * (Tn / kUnitShards + 1);
+        w.units.cap_full = (uint32_t)(cf > 0xFFFFFFFFull ? 0xFFFFFFFFull : cf);
+        w.units.cap_part = (uint32_t)cp;
+        w.units.units = (uint2 *)(b + o); o += align_up(kUnitShards * w.units.shard_stride() * sizeof(uint2));
+    }
     w.grad_rows = nullptr;                          // backward-only, sized from instances_emitted: gsr_backward_rows_size
     w.total = o;
     return w;
@@ -155,7 +159,8 @@ size_t binning_clear_bytes(const FrameK &f, const ImageWS &iw)
     // the per-chunk tile ranges and, directly behind them, the per-tile counters with their padding (carve_image: both are
     // 256-byte aligned blocks, so the size is a multiple of 16)
     const size_t Tn = (size_t)f.Gx * f.Gy;
-    return (size_t)((char *)iw.tile_cnt - (char *)iw.ranges) + align_up((Tn ? Tn : 1) * sizeof(uint32_t));
+    (void)Tn;
+    return (size_t)((char *)iw.unit_count - (char *)iw.ranges) + align_up(kUnitShards * kUnitClasses * sizeof(uint32_t));
 }
 
 int launch_binning_init(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s, bool ranges_cleared, CtrlMirror mirror)

@@ -6,7 +6,6 @@
 // 48 (screen grads) + 44 + 12K + 5 and writes 40 + 12M.  Camera matrices are wave-uniform loads that
 // the compiler scalarises (s_load) — they never cost vector memory bandwidth.
 #include "gsr_internal.h"
-#include "gsr_bwd_units.h"
 
 namespace gsr {
 
@@ -483,10 +482,12 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
                                                                 const float *__restrict__ shs, const float *__restrict__ shs_rest,
                                                                 int has_colpre, const int32_t *__restrict__ radii,
                                                                 const uint8_t *__restrict__ clamped,
-                                                                const float4 *__restrict__ screen, gsr_grads out)
+                                                                const float4 *__restrict__ screen, gsr_grads out,
+                                                                const uint32_t *__restrict__ cnt_open)
 {
     const int r = blockIdx.x * kGeomBlock + threadIdx.x;
     if (r >= n_ranks) return;
+    if (cnt_open && cnt_open[r] == 0u) return;   // this frame binned no instance of the rank: its screen-space row is zero (or was never written)
     const int i = (int)order[r];
     if (i < 0 || i >= f.P) return;               // (an exchange list entry nobody filled: -1)
     if (radii[i] <= 0) return;
@@ -546,20 +547,9 @@ struct ZeroSegs {
     int n;
 };
 
-// UNITS: block 0 builds the blend backward's work-unit list instead of filling (gsr_bwd_units.h): the frame's forward is
-// complete when this kernel runs, nothing reads the list before the backward, and the job (one block, ~10 us) disappears
-// behind the other blocks' 45 us of stores: no launch, no stream time of its own.
-template <bool UNITS>
-__global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z, BwdUnitArgs ua)
+__global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z)
 {
-    unsigned block = blockIdx.x, blocks = gridDim.x;
-    if constexpr (UNITS) {
-        if (blockIdx.x == 0) {
-            bwd_units_block<kGeomBlock, 16>(ua);
-            return;
-        }
-        block -= 1; blocks -= 1;
-    }
+    const unsigned block = blockIdx.x, blocks = gridDim.x;
     const size_t total = z.end[z.n - 1];
     const size_t stride = (size_t)blocks * kGeomBlock * 4;
     for (size_t v = ((size_t)block * kGeomBlock + threadIdx.x) * 4; v < total; v += stride) {
@@ -576,7 +566,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z, BwdUni
 
 // zero-fill of the backward's outputs in ONE launch: screen-space gradients (optional) + every wanted parameter gradient
 int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
-                        const BwdUnitArgs *units, uint8_t *row_valid, size_t valid_bytes)
+                        uint8_t *row_valid, size_t valid_bytes)
 {
     const size_t P = (size_t)f.P;
     ZeroSegs z;
@@ -599,21 +589,18 @@ int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, 
     const size_t total = z.end[z.n - 1];
     size_t blocks = (total / 4 + kGeomBlock - 1) / kGeomBlock / 4 + 1;
     if (blocks > 8192) blocks = 8192;
-    if (units && units->n_tiles > 0 && units->chunks_run > 0)
-        hipLaunchKernelGGL(k_zero_segments<true>, dim3((unsigned)blocks + 1), dim3(kGeomBlock), 0, s, z, *units);
-    else
-        hipLaunchKernelGGL(k_zero_segments<false>, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z, BwdUnitArgs{});
+    hipLaunchKernelGGL(k_zero_segments, dim3((unsigned)blocks), dim3(kGeomBlock), 0, s, z);
     GSR_LAUNCH_CHECK("zero_outputs", false, s);
     return GSR_OK;
 }
 
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
                     const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s,
-                    const uint32_t *rows)
+                    const uint32_t *rows, bool own_frame_sparse)
 {
     if (g1 <= g0) return GSR_OK;
     if (!rows) rows = gw.order;                  // the frame's own binned prefix
-    if (n_ranks >= 0 && g0 == 0 && g1 == f.P && (long long)n_ranks * 4 < (long long)f.P) {
+    if (n_ranks >= 0 && g0 == 0 && g1 == f.P && (own_frame_sparse || (long long)n_ranks * 4 < (long long)f.P)) {
         // depth-complex frame: almost every gradient row is zero -> memset the outputs, then visit the binned prefix only
         ProfileScope prof("geom_bwd", s);
         int rc0;
@@ -624,7 +611,7 @@ int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians 
     hipLaunchKernelGGL((k_geom_bwd_sparse<DEG, RAW>), dim3(sgrid), dim3(kGeomBlock), 0, s, f, n_ranks, rows, cam.viewmatrix, \
                        cam.projmatrix, cam.campos, g.means3D, g.scales, g.rotations, g.cov3D_precomp, g.opacities, g.shs,      \
                        g.shs_rest, g.colors_precomp ? 1 : 0, radii, gw.clamped, reinterpret_cast<const float4 *>(screen_grads),   \
-                       out)
+                       out, own_frame_sparse ? gw.cnt_open : nullptr)
             switch ((!g.raw ? 0 : (raw_split_sh(f, g) ? 1 : 2)) * 4 + (f.D > 3 ? 3 : (f.D < 0 ? 0 : f.D))) {
                 case 0: GSR_GS(0, 0); break;  case 1: GSR_GS(1, 0); break;  case 2: GSR_GS(2, 0); break;  case 3: GSR_GS(3, 0); break;
                 case 4: GSR_GS(0, 1); break;  case 5: GSR_GS(1, 1); break;  case 6: GSR_GS(2, 1); break;  case 7: GSR_GS(3, 1); break;

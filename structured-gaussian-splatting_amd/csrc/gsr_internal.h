@@ -131,20 +131,40 @@ struct GeomWS {                 // O(P): the reference's geomBuffer
 // leaves the per-pixel state (T, colour) at every segment boundary (a checkpoint), so the segments of one tile are independent
 // work units: (tile, chunk, segment).  kSeg list entries are ~25 us of one wave; a 400-entry tile as ONE unit was 100 us and the
 // launch ended with a third of its time draining (two rounds of 4096 resident waves, tail = the last-started tiles).
+// The forward's wave of a (tile, chunk) appends the pair's units itself when it is done — one returning atomic on one of
+// kUnitShards counters (shard = tile % 8), so that the list costs no kernel and no block of its own — and the backward reads
+// every shard's list BACKWARDS: the tiles that finish the forward last are the long ones, and the launch should start with them.
 #ifndef GSR_BWD_SEG
 #define GSR_BWD_SEG 128
 #endif
 constexpr int kSeg = GSR_BWD_SEG;
 static_assert(kSeg % kWave == 0, "segments are whole 64-entry batches");
 constexpr int kCkptFloats = 16 * kWave;   // one checkpoint = (T, r, g, b) of the tile's 256 pixels: [quadrant][field][lane], 4 KB
-constexpr int kUnitTileBits = 24;         // BwdUnit.x = tile | chunk << 24; .y = segment | last-segment flag << 31
-constexpr uint32_t kUnitLast = 1u << 31;
+constexpr int kUnitTileBits = 24;         // BwdUnit.x = tile | chunk << 24; .y = segment
+constexpr int kUnitShards = 8;
+// ... in kUnitClasses lists per shard, longest first: full segments, then the pairs' last, partial segments in 16 length classes of
+// kSeg / 16 entries.  The launch ends when the last-started units finish: started in arbitrary order (any unit last) K7 took 618 us
+// at cfg3n, longest first 564; cfg3's 8 160 units are nearly all partial (two rounds of 4 096 waves): 4 classes cost it 17 us.
+constexpr int kUnitPartClasses = 16;
+constexpr int kUnitClasses = 1 + kUnitPartClasses;
+static_assert(kSeg % kUnitPartClasses == 0, "length classes of whole entries");
+__host__ __device__ inline int unit_class(uint32_t rest) { return kUnitPartClasses - (int)(rest / (kSeg / kUnitPartClasses)); }      // rest in 1 .. kSeg - 1
+struct UnitLists {             // where a shard's five lists live inside BinningWS::units
+    uint2 *units; uint32_t cap_full, cap_part;
+    __host__ __device__ size_t shard_stride() const { return (size_t)cap_full + (size_t)(kUnitClasses - 1) * cap_part; }
+    __host__ __device__ size_t list_begin(int shard, int cls) const
+    {
+        return (size_t)shard * shard_stride() + (cls == 0 ? 0 : (size_t)cap_full + (size_t)(cls - 1) * cap_part);
+    }
+    __host__ __device__ uint32_t list_cap(int cls) const { return cls == 0 ? cap_full : cap_part; }
+};
 
 struct ImageWS {                // O(N + Tn): the reference's imgBuffer
     float *T_state;             // [N]  running / final transmittance; negative = pixel hit the cut-off
     int32_t *last_enc;          // [N]  (chunk + 1) << 26 | contributor position in that chunk's range
     uint2 *ranges;              // [GSR_MAX_CHUNKS][Tn]
     uint32_t *tile_cnt;         // [Tn] instances per tile of the chunk being binned (gather variant; zero between chunks)
+    uint32_t *unit_count;       // [kUnitShards][kUnitClasses] work units of the blend backward appended so far (cleared with the ranges and counters)
     uint32_t *open;             // [Tn] 1 = tile still has an unsaturated pixel (0 outside the slab)
     unsigned long long *open_bits;   // [Gy][ceil(Gx/64)] the same flags, one bit per tile (rebuilt at chunk boundaries)
     uint32_t *tile_walk;        // [GSR_MAX_CHUNKS][Tn] entries of chunk c's range the backward walks: the tile's deepest contributor
@@ -162,9 +182,8 @@ struct BinningWS {              // O(R): the reference's binningBuffer
                                 //      forward's zero fill, or by gsr_backward_render itself)
     float *ckpt;                // [R / kSeg + 2][kCkptFloats] the pixels' state in front of sorted position p = range start + k kSeg
                                 //      (k >= 1), at slot p / kSeg: ranges are disjoint, so the slots are
-    uint2 *units;               // [R / kSeg + GSR_MAX_CHUNKS Tn + 1] work units of the blend backward, longest first
-    uint32_t *n_units;          // [1]
-    size_t unit_capacity;
+    UnitLists units;            // [kUnitShards] x (full segments [R / kSeg + 1], 16 classes of partial ones [GSR_MAX_CHUNKS (Tn / 8 + 1)] each):
+                                // work units of the blend backward, each list in the order the forward's waves finished
     float *grad_rows;           // [instances emitted, kRowFloats] per-instance screen-space gradient rows, by slot: the caller's
                                 // backward-time allocation (gsr_backward_rows_size), not part of the carved block
     size_t total;
@@ -220,23 +239,28 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s);
 // rows_upper: bound of the instances the chunks that ran emitted (sizes the launch: the unit count lives on the device)
 int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long long rows_upper, const GeomWS &gw, BinningWS &bw,
-                      const ImageWS &iw, const float *out_color, const float *dL_dcolor, bool debug, hipStream_t s, bool units_ready = false);
-// The unit list of the blend backward (gsr_bwd_units.h): what one block needs to build it.
-struct BwdUnitArgs {
-    int n_tiles, tile_base, Tn, chunks_run;       // the slab's tiles are tile_base .. tile_base + n_tiles
-    const uint2 *ranges; const uint32_t *tile_walk;
-    uint2 *units; uint32_t *n_units; uint32_t capacity;
-};
-BwdUnitArgs bwd_unit_args(const FrameK &f, int chunks_run, const BinningWS &bw, const ImageWS &iw);
-// units: also build the blend backward's unit list inside the fill (block 0 of the launch) and clear `valid_bytes` bytes of
-// its row-valid flags
+                      const ImageWS &iw, const float *out_color, const float *dL_dcolor, bool debug, hipStream_t s);
+// row_valid / valid_bytes: also clear that many bytes of the blend backward's row-valid flags
 int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
-                        const BwdUnitArgs *units = nullptr, uint8_t *row_valid = nullptr, size_t valid_bytes = 0);
-int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
-                       float *screen_grads, int prezeroed, bool debug, hipStream_t s);
+                        uint8_t *row_valid = nullptr, size_t valid_bytes = 0);
+int launch_reduce_rows(const FrameK &f, const gsr_frame_plan &plan, const GeomWS &gw, const BinningWS &bw, float *screen_grads,
+                       int prezeroed, bool debug, hipStream_t s);
+// Depth ranks that can own a gradient, as far as the host knows: the chunks that ran, a chunk that went through the live filter
+// counted as nothing (only the Gaussians that still reached an open tile were binned: few, and how few is the device's knowledge).
+// Decides "sparse geometry backward + zero fill" against "dense geometry backward" (sparse below P / 4).
+inline long long effective_binned_ranks(const gsr_frame_plan &plan)
+{
+    long long n = 0;
+    const int chunks = (plan.num_rendered > 0 && plan.chunks_run > 0) ? plan.chunks_run : 0;
+    for (int c = 0; c < chunks && c < GSR_MAX_CHUNKS; ++c)
+        if (!((plan.chunks_filtered >> c) & 1)) n += plan.chunk_rank_begin[c + 1] - plan.chunk_rank_begin[c];
+    return n;
+}
+// own_frame_sparse: the gradients are this frame's own (gsr_backward_render of the same plan) and the sparse path was chosen from
+// effective_binned_ranks: ranks that emitted no instance (GeomWS::cnt_open) are skipped before anything of theirs is read
 int launch_geom_bwd(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, const int32_t *radii, const GeomWS &gw,
                     const float *screen_grads, int g0, int g1, int n_ranks, const gsr_grads &out, bool debug, hipStream_t s,
-                    const uint32_t *rows = nullptr);
+                    const uint32_t *rows = nullptr, bool own_frame_sparse = false);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 
 }  // namespace gsr

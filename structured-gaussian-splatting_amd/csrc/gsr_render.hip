@@ -15,7 +15,6 @@
 //     accepts skip the reduction (wave-uniform ballot) and their row is never written (one valid byte per row).
 //   * workgroup = one wave (64 threads); forward: tile = block (consecutive tiles run on different XCDs).
 #include "gsr_internal.h"
-#include "gsr_bwd_units.h"
 
 namespace gsr {
 
@@ -219,7 +218,8 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
                                                       const float4 *__restrict__ records, const float *__restrict__ bg,
                                                       float *__restrict__ out_color, float *__restrict__ T_state,
                                                       int32_t *__restrict__ last_enc, uint32_t *__restrict__ tile_walk_c,
-                                                      float *__restrict__ ckpt, float *__restrict__ ckpt_start_c)
+                                                      float *__restrict__ ckpt, float *__restrict__ ckpt_start_c,
+                                                      UnitLists units, uint32_t *__restrict__ unit_count)
 {
     __shared__ float4 sh_rec[kWave * 3];
 #ifdef GSR_FWD_TRACE
@@ -335,6 +335,24 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
         open[tile] = closing ? 0u : (stuck ? 2u : 1u);
         tile_walk_c[tile] = (uint32_t)walked;
     }
+    // the blend backward's work units of this (tile, chunk): one per kSeg walked entries, appended to the lists of the tile's shard
+    // (full segments; the last, partial one by its length class)
+    const uint32_t n_full = (uint32_t)walked / kSeg, rest = (uint32_t)walked - n_full * kSeg;
+    if (walked > 0) {
+        const int shard = t & (kUnitShards - 1);
+        const uint32_t head = (uint32_t)tile | ((uint32_t)c << kUnitTileBits);
+        const int cls = unit_class(rest);
+        uint32_t at_full = 0, at_part = 0;
+        if (lane == 0) {
+            if (n_full) at_full = atomicAdd(&unit_count[shard * kUnitClasses], n_full);
+            if (rest) at_part = atomicAdd(&unit_count[shard * kUnitClasses + cls], 1u);
+        }
+        at_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)at_full);
+        uint2 *full = units.units + units.list_begin(shard, 0);
+        for (uint32_t sgm = (uint32_t)lane; sgm < n_full; sgm += kWave)
+            if (at_full + sgm < units.cap_full) full[at_full + sgm] = make_uint2(head, sgm);
+        if (lane == 0 && rest && at_part < units.cap_part) units.units[units.list_begin(shard, cls) + at_part] = make_uint2(head, n_full);
+    }
 }
 
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
@@ -347,7 +365,7 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
     hipLaunchKernelGGL(k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, c, last_chunk ? 1 : 0,
                        iw.ranges + (size_t)c * Tn, iw.open, bw.sorted_gid, gw.records, cam.bg, out_color, iw.T_state,
                        iw.last_enc, iw.tile_walk + (size_t)c * Tn, bw.ckpt,
-                       c > 0 ? iw.ckpt_start + (size_t)(c - 1) * Tn * kCkptFloats : nullptr);
+                       c > 0 ? iw.ckpt_start + (size_t)(c - 1) * Tn * kCkptFloats : nullptr, bw.units, iw.unit_count);
     GSR_LAUNCH_CHECK("render_fwd", debug, s);
     return GSR_OK;
 }
@@ -456,20 +474,6 @@ __device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &s
     return bwd_pair<3>(sp, lp, dx, dy, pos, P, A);
 }
 
-// The unit list (gsr_bwd_units.h) in its own launch: only when the forward's zero fill did not carry it (k_zero_segments<true>,
-// gsr_geom.hip).
-__global__ __launch_bounds__(1024) void k_bwd_units(BwdUnitArgs a) { bwd_units_block<1024, 8>(a); }
-
-BwdUnitArgs bwd_unit_args(const FrameK &f, int chunks_run, const BinningWS &bw, const ImageWS &iw)
-{
-    BwdUnitArgs a;
-    a.n_tiles = (f.ty1 - f.ty0) * f.Gx; a.tile_base = f.ty0 * f.Gx; a.Tn = f.Gx * f.Gy; a.chunks_run = chunks_run;
-    a.ranges = iw.ranges; a.tile_walk = iw.tile_walk;
-    a.units = bw.units; a.n_units = bw.n_units;
-    a.capacity = (uint32_t)(bw.unit_capacity > 0xFFFFFFFFull ? 0xFFFFFFFFull : bw.unit_capacity);
-    return a;
-}
-
 __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, const uint2 *__restrict__ ranges,
                                                       const uint32_t *__restrict__ tile_walk,
                                                       const uint32_t *__restrict__ sorted_gid, const uint32_t *__restrict__ sorted_slot,
@@ -477,14 +481,22 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
                                                       const float *__restrict__ T_state, const int32_t *__restrict__ last_enc,
                                                       const float *__restrict__ dL_dpix, const float *__restrict__ ckpt,
                                                       const float *__restrict__ ckpt_start, float4 *__restrict__ grad_rows,
-                                                      uint8_t *__restrict__ row_valid, const uint2 *__restrict__ units,
-                                                      const uint32_t *__restrict__ n_units_ptr)
+                                                      uint8_t *__restrict__ row_valid, UnitLists units,
+                                                      const uint32_t *__restrict__ unit_count)
 {
     __shared__ float4 sh_rec[kWave * 3];
 #ifdef GSR_BWD_TRACE
     TraceEnd trace_end{(unsigned long long)wall_clock64(), (int)blockIdx.x};
 #endif
-    const uint32_t n_units = *n_units_ptr;
+    // block b serves shard b % 8: its lists one after the other (full segments first, then the partial ones by length class)
+    const int shard = (int)(blockIdx.x & (kUnitShards - 1));
+    uint32_t list_end[kUnitClasses];             // running ends of the lists in the shard's unit numbering (wave-uniform)
+    {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < kUnitClasses; ++k) { run += min(unit_count[shard * kUnitClasses + k], units.list_cap(k)); list_end[k] = run; }
+    }
+    const uint32_t n_units = list_end[kUnitClasses - 1];
     const size_t Tn = (size_t)f.Gx * f.Gy;
     const int lane = threadIdx.x;
     const size_t N = (size_t)f.W * f.H;
@@ -493,10 +505,12 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
     const int h31 = lane & 31;
     const int row_off = h31 == 8 ? 3 : h31 == 12 ? 4 : h31 == 16 ? 5 : h31 == 20 ? 6 : h31 == 24 ? 8 : -1;
     const float row_mul = (h31 == 8 || h31 == 12) ? -0.5f : 1.f;
-    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const uint2 unit = units[u];
+    for (uint32_t u = blockIdx.x / kUnitShards; u < n_units; u += gridDim.x / kUnitShards) {
+        int cls = 0;
+        for (int k = 0; k < kUnitClasses - 1; ++k) cls += u >= list_end[k] ? 1 : 0;
+        const uint2 unit = units.units[units.list_begin(shard, cls) + (u - (cls ? list_end[cls - 1] : 0u))];
         const int tile = (int)(unit.x & ((1u << kUnitTileBits) - 1u)), c = (int)(unit.x >> kUnitTileBits);
-        const int sgm = (int)(unit.y & ~kUnitLast);
+        const int sgm = (int)unit.y;
         const int ty = tile / f.Gx, tx = tile - ty * f.Gx;
         const int px0 = tx * GSR_TILE + lane_px(lane), py0 = ty * GSR_TILE + lane_py(lane);
         const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 8.f;
@@ -640,24 +654,19 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
 }
 
 int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long long rows_upper, const GeomWS &gw, BinningWS &bw,
-                      const ImageWS &iw, const float *out_color, const float *dL_dcolor, bool debug, hipStream_t s, bool units_ready)
+                      const ImageWS &iw, const float *out_color, const float *dL_dcolor, bool debug, hipStream_t s)
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0 || chunks_run <= 0) return GSR_OK;
-    if (!units_ready) {
-        ProfileScope prof("bwd_units", s);
-        hipLaunchKernelGGL(k_bwd_units, dim3(1), dim3(1024), 0, s, bwd_unit_args(f, chunks_run, bw, iw));
-        GSR_LAUNCH_CHECK("bwd_units", debug, s);
-    }
-    // one block per unit while they fit the grid; the count is the device's (gsr_bwd_units.h), the bound the host's: every
-    // (tile, chunk) pair has at most n / kSeg + 1 units
-    long long grid = rows_upper / kSeg + (long long)n_tiles * chunks_run + 1;
-    if (grid > (long long)bw.unit_capacity) grid = (long long)bw.unit_capacity;
-    if (grid > (1 << 16)) grid = 1 << 16;
+    // one block per unit while they fit the grid; the counts are the device's (the forward appended the units), the bound the
+    // host's: a (tile, chunk) pair has at most n / kSeg + 1 units.  Blocks are dealt to the shards round-robin.
+    long long per_shard = (rows_upper / kSeg + (long long)n_tiles * chunks_run) / kUnitShards + 1;
+    if (per_shard > (long long)bw.units.shard_stride()) per_shard = (long long)bw.units.shard_stride();
+    if (per_shard > (1 << 13)) per_shard = 1 << 13;
     ProfileScope prof("render_bwd", s);
-    hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)grid), dim3(kWave), 0, s, f, iw.ranges, iw.tile_walk, bw.sorted_gid, bw.vals[sort_result], gw.records, out_color,
-                       iw.T_state, iw.last_enc, dL_dcolor, bw.ckpt, iw.ckpt_start, reinterpret_cast<float4 *>(bw.grad_rows), bw.row_valid,
-                       bw.units, bw.n_units);
+    hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)(per_shard * kUnitShards)), dim3(kWave), 0, s, f, iw.ranges, iw.tile_walk, bw.sorted_gid,
+                       bw.vals[sort_result], gw.records, out_color, iw.T_state, iw.last_enc, dL_dcolor, bw.ckpt, iw.ckpt_start,
+                       reinterpret_cast<float4 *>(bw.grad_rows), bw.row_valid, bw.units, iw.unit_count);
     GSR_LAUNCH_CHECK("render_bwd", debug, s);
     return GSR_OK;
 }
@@ -669,7 +678,7 @@ int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long lon
 // Only ranks of chunks that actually ran can own rows; every other Gaussian's gradient row is zero (memset).
 constexpr int kRedBlock = 256;
 template <int kRedGroup>
-__global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const uint32_t *__restrict__ order,
+__global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int r_begin, int n_ranks, const uint32_t *__restrict__ order,
                                                            const uint32_t *__restrict__ cnt_open,
                                                            const uint32_t *__restrict__ row_begin,
                                                            const uint8_t *__restrict__ row_valid,
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const ui
                                                            int write_empty)
 {
     const int sub = threadIdx.x & (kRedGroup - 1);
-    const int r = (blockIdx.x * kRedBlock + threadIdx.x) / kRedGroup;
+    const int r = r_begin + (blockIdx.x * kRedBlock + threadIdx.x) / kRedGroup;
     const bool live = r < n_ranks;
     const uint32_t cnt = live ? cnt_open[r] : 0u;
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
@@ -705,8 +714,12 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int n_ranks, const ui
     }
 }
 
-int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const GeomWS &gw, const BinningWS &bw,
-                       float *screen_grads, int prezeroed, bool debug, hipStream_t s)
+// One launch per depth chunk that ran, each with its own lanes-per-Gaussian: a whole wave where the chunk's Gaussians own many
+// rows each (the nearest, screen-filling splats: a few thousand rows), eight otherwise — and always eight for a chunk that went
+// through the live filter, whose instance bound says nothing about what it emitted (a training frame's last chunk is most of the
+// scene with a bound of tens of millions: 64 lanes for each of its 1e6 ranks was 100 us of idle threads).
+int launch_reduce_rows(const FrameK &f, const gsr_frame_plan &plan, const GeomWS &gw, const BinningWS &bw, float *screen_grads,
+                       int prezeroed, bool debug, hipStream_t s)
 {
     // prezeroed: 0 = clear the whole tensor first; 1 = the caller already has; 2 = only the rows of the binned prefix will ever
     // be read (the sparse geometry backward of the same frame): every prefix row is written, zeros included, nothing else
@@ -714,17 +727,19 @@ int launch_reduce_rows(const FrameK &f, int n_ranks, long long rows_upper, const
     ProfileScope prof("reduce_rows", s);
     if (prezeroed == 0) GSR_HIP_CHECK(hipMemsetAsync(screen_grads, 0, (size_t)f.P * kRowFloats * sizeof(float), s));
     const int write_empty = prezeroed == 2 ? 1 : 0;
-    if (n_ranks > 0) {
-        // lanes per Gaussian: a whole wave when the processed Gaussians own many rows each (depth-complex scenes:
-        // a few thousand screen-filling splats), eight otherwise
-        const bool wide = rows_upper / (long long)n_ranks >= 48;
-        const long long threads = (long long)n_ranks * (wide ? 64 : 8);
+    const int chunks = (plan.num_rendered > 0 && plan.chunks_run > 0) ? plan.chunks_run : 0;
+    for (int c = 0; c < chunks && c < GSR_MAX_CHUNKS; ++c) {
+        const int r0 = plan.chunk_rank_begin[c], r1 = plan.chunk_rank_begin[c + 1];
+        if (r1 <= r0) continue;
+        const bool filtered = (plan.chunks_filtered >> c) & 1;
+        const bool wide = !filtered && plan.chunk_instances_max[c] / (long long)(r1 - r0) >= 48;
+        const long long threads = (long long)(r1 - r0) * (wide ? 64 : 8);
         const dim3 grid((unsigned)((threads + kRedBlock - 1) / kRedBlock));
         if (wide)
-            hipLaunchKernelGGL(k_reduce_rows<64>, grid, dim3(kRedBlock), 0, s, n_ranks, gw.order, gw.cnt_open, gw.row_begin,
+            hipLaunchKernelGGL(k_reduce_rows<64>, grid, dim3(kRedBlock), 0, s, r0, r1, gw.order, gw.cnt_open, gw.row_begin,
                                bw.row_valid, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
         else
-            hipLaunchKernelGGL(k_reduce_rows<8>, grid, dim3(kRedBlock), 0, s, n_ranks, gw.order, gw.cnt_open, gw.row_begin,
+            hipLaunchKernelGGL(k_reduce_rows<8>, grid, dim3(kRedBlock), 0, s, r0, r1, gw.order, gw.cnt_open, gw.row_begin,
                                bw.row_valid, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
     }
     GSR_LAUNCH_CHECK("reduce_rows", debug, s);

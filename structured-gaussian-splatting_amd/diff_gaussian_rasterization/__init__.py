@@ -65,10 +65,10 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def _binning_bytes(n: int, tiles: int) -> int:
     """gsr_binning_size(desc, n) without the call (csrc/gsr_binning.hip carve_binning; tests/test_abi.py holds the two together):
-    six u32 arrays and one byte array of max(n, 1) entries, one 4 KB checkpoint per `seg` instances (+ 2), the blend backward's
-    unit list (n / seg + 8 tiles + 1 units of 8 bytes) and its count, each block padded to 256 bytes."""
+    six u32 arrays and one byte array of max(n, 1) entries, one 4 KB checkpoint per `seg` instances (+ 2) and the blend backward's
+    unit lists (per shard n / seg + 1 full and 16 x 8 (tiles / 8 + 1) partial units of 8 bytes), each block padded to 256 bytes."""
     n, seg, up = max(int(n), 1), N.bwd_segment_entries(), lambda b: (b + 255) // 256 * 256
-    return 6 * up(4 * n) + up(n) + up((n // seg + 2) * 4096) + up((n // seg + N.MAX_CHUNKS * int(tiles) + 1) * 8) + 256
+    return 6 * up(4 * n) + up(n) + up((n // seg + 2) * 4096) + up(8 * (n // seg + 1 + 16 * N.MAX_CHUNKS * (int(tiles) // 8 + 1)) * 8)
 
 
 _binning_guess = {}        # (P, W, H, slab, device) -> instances the binning workspace of that frame shape last had to hold
@@ -266,7 +266,7 @@ def prepare_backward(fr: "_Frame", needs, screen_prefix_only: bool = False) -> N
     # ctx.needs_input_grad stays True for leaf parameters under torch.no_grad() (eval / test-view renders): no backward can follow
     if P == 0 or plan.num_rendered <= 0 or plan.chunks_run <= 0 or not any(needs) or not caller_grad_enabled():
         return
-    if int(plan.chunk_rank_begin[plan.chunks_run]) * 4 >= P:
+    if N.effective_binned_ranks(plan) * 4 >= P:
         return                                  # the dense geometry backward writes every row itself
     needs = tuple(bool(x) for x in needs)
     if fr.pre is None or fr.pre["needs"] != needs:
@@ -306,11 +306,13 @@ def rasterize_backward_geom(fr: "_Frame", screen: torch.Tensor, needs, g0: int =
             if rows is not None and not partial:
                 N.backward_geom_rows(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, rows, grads, dev)
                 binned_ranks = -2
-            elif binned_ranks is None:        # gradients of this very frame: its own binned depth prefix
-                plan = fr.plan
+            own = None
+            if rows is None and binned_ranks is None:        # gradients of this very frame: its own binned depth prefix
+                plan = own = fr.plan
                 binned_ranks = int(plan.chunk_rank_begin[plan.chunks_run]) if plan.num_rendered > 0 and plan.chunks_run > 0 else 0
             if binned_ranks != -2:
-                N.backward_geom(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, g0, g1, grads, dev, binned_ranks)
+                N.backward_geom(fr.desc, fr.cam, fr.gauss, fr.radii, fr.geom_ws, screen, g0, g1, grads, dev, binned_ranks,
+                                own_plan=None if partial else own)
     if fr.raw:
         return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov, g_rest
     return g_means3D, g_means2D, g_sh, g_col, g_op, g_sc, g_rot, g_cov

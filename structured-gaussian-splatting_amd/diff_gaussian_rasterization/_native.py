@@ -60,7 +60,7 @@ class DebugViews(C.Structure):
     _fields_ = [("splat_records", C.c_void_p), ("tiles_touched", C.c_void_p), ("depth_order", C.c_void_p),
                 ("point_offsets", C.c_void_p), ("clamped", C.c_void_p), ("sorted_gaussian", C.c_void_p),
                 ("ranges", C.c_void_p), ("final_T", C.c_void_p), ("n_contrib", C.c_void_p), ("tile_walk", C.c_void_p),
-                ("bwd_units", C.c_void_p), ("bwd_unit_count", C.c_void_p), ("bwd_unit_capacity", C.c_uint64)]
+                ("bwd_units", C.c_void_p), ("bwd_unit_count", C.c_void_p), ("bwd_unit_cap_full", C.c_uint32), ("bwd_unit_cap_part", C.c_uint32)]
 
 
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess", "gsr_forward",
@@ -205,10 +205,19 @@ def bwd_segment_entries() -> int:
 
 
 def backward_geom(desc, cam: Camera, g: Gaussians, radii, geom_ws, screen_grads, g0, g1, grads: Grads, device,
-                  binned_ranks: int = -1):
+                  binned_ranks: int = -1, own_plan: Optional[FramePlan] = None):
+    """own_plan: the frame's plan when screen_grads are this very frame's (gsr_backward_render of the same plan), else None."""
     _check(load().gsr_backward_geom(C.byref(desc), C.byref(cam), C.byref(g), _ptr(radii), _ptr(geom_ws),
-                                    _ptr(screen_grads), C.c_int32(g0), C.c_int32(g1), C.c_int32(binned_ranks), C.byref(grads),
-                                    _stream(device)), "gsr_backward_geom")
+                                    _ptr(screen_grads), C.c_int32(g0), C.c_int32(g1), C.c_int32(binned_ranks),
+                                    None if own_plan is None else C.byref(own_plan), C.byref(grads), _stream(device)), "gsr_backward_geom")
+
+
+def effective_binned_ranks(plan: FramePlan) -> int:
+    """csrc/gsr_internal.h effective_binned_ranks: the ranks of the chunks that ran, a live-filtered chunk counted as nothing."""
+    if plan.num_rendered <= 0 or plan.chunks_run <= 0:
+        return 0
+    return sum(int(plan.chunk_rank_begin[c + 1]) - int(plan.chunk_rank_begin[c]) for c in range(int(plan.chunks_run))
+               if not (int(plan.chunks_filtered) >> c) & 1)
 
 
 def backward_geom_rows(desc, cam: Camera, g: Gaussians, radii, geom_ws, screen_grads, rows, grads: Grads, device):
@@ -281,9 +290,11 @@ def debug_views(desc, geom_ws, binning_ws, image_ws, plan: FramePlan) -> dict:
         final_T=view(image_ws, v.final_T, N * 4, torch.float32, (desc.height, desc.width)),
         n_contrib=view(image_ws, v.n_contrib, N * 4, torch.int32, (desc.height, desc.width)),
         tile_walk=view(image_ws, v.tile_walk, MAX_CHUNKS * Tn * 4, torch.int32, (MAX_CHUNKS, Tn)),
-        # (tile | chunk << 24, segment | last << 31) per work unit of the blend backward; the count lives on the device
-        bwd_units=view(binning_ws, v.bwd_units, int(v.bwd_unit_capacity) * 8, torch.int32, (int(v.bwd_unit_capacity), 2)),
-        bwd_unit_count=view(binning_ws, v.bwd_unit_count, 4, torch.int32, (1,)))
+        # (tile | chunk << 24, segment) per work unit of the blend backward: per shard 17 lists [cap_full + 16 cap_part], their lengths
+        bwd_units=view(binning_ws, v.bwd_units, 8 * (int(v.bwd_unit_cap_full) + 16 * int(v.bwd_unit_cap_part)) * 8, torch.int32,
+                       (8, int(v.bwd_unit_cap_full) + 16 * int(v.bwd_unit_cap_part), 2)),
+        bwd_unit_caps=(int(v.bwd_unit_cap_full), int(v.bwd_unit_cap_part)),
+        bwd_unit_count=view(image_ws, v.bwd_unit_count, 8 * 17 * 4, torch.int32, (8, 17)))
 
 
 def profile_enable(on: bool):

@@ -40,9 +40,9 @@ def test_argument_validation_without_gpu(native):
     ok = native.make_desc(1000, 3, 16, 100, 60, 0.5, 0.5, 1.0, False, False)
     gb, ib = native.workspace_sizes(ok)
     assert gb >= 1000 * 57 and ib >= 100 * 60 * 8 + 7 * 4 * 8
-    # six u32 and one flag byte per instance, one 4 KB checkpoint per segment of them, the blend backward's unit list
+    # six u32 and one flag byte per instance, one 4 KB checkpoint per segment of them, the blend backward's unit lists
     seg = native.bwd_segment_entries()
-    assert 5000 * 25 + (5000 // seg) * 4096 <= native.binning_size(ok, 5000) < 5000 * 25 + (5000 // seg + 2) * 4096 + 8 * (5000 // seg + 8 * 28 + 1) + 4096
+    assert 5000 * 25 + (5000 // seg) * 4096 <= native.binning_size(ok, 5000) < 5000 * 25 + (5000 // seg + 2) * 4096 + 64 * (5000 // seg + 1 + 16 * 8 * 5) + 4096
     # backward-only gradient rows: 48 B per EMITTED instance; the emission bound when the count stayed on the device
     plan = native.FramePlan(); plan.instances_emitted = 1234
     assert 1234 * 48 <= native.backward_rows_size(ok, plan) < 1234 * 48 + 512

@@ -1307,17 +1307,14 @@ def test_one_call_forward_falls_back_when_the_guessed_workspace_is_too_small():
 
 
 def _check_bwd_units(fr, v, W, H, rows):
-    """The blend backward's unit list against the frame: every (tile, chunk) pair whose range is not empty is covered by the
-    segments 0 .. ceil(walk / SEG) - 1 exactly once (one segment, flagged last, when nothing is walked), the last segment of
-    each pair carries the flag, and the list is ordered longest unit first (full segments, then partial ones by length)."""
+    """The blend backward's unit lists against the frame: every (tile, chunk) pair with walked entries is covered by the
+    segments 0 .. ceil(walk / SEG) - 1 exactly once, in the shard of its tile (slab-relative index % 8)."""
     from diff_gaussian_rasterization import _native as N
     SEG = N.bwd_segment_entries()
     Gx, Gy = (W + 15) // 16, (H + 15) // 16
     ty0, ty1 = (0, Gy) if rows is None else rows
-    n_units = int(v["bwd_unit_count"][0])
-    units = v["bwd_units"][:n_units].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-    tile, chunk = units[:, 0] & ((1 << 24) - 1), units[:, 0] >> 24
-    seg, last = units[:, 1] & 0x7FFFFFFF, units[:, 1] >> 31
+    counts = v["bwd_unit_count"].cpu().numpy().astype(np.int64)
+    lists = v["bwd_units"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     rng = v["ranges"].long().cpu().numpy()[:fr.plan.chunks_run]
     lens = rng[..., 1] - rng[..., 0]
     walk = np.minimum(v["tile_walk"].long().cpu().numpy()[:fr.plan.chunks_run], lens)
@@ -1325,33 +1322,42 @@ def _check_bwd_units(fr, v, W, H, rows):
     # names; with several chunks the earlier ones' depths are a lower bound)
     enc = v["n_contrib"].long().cpu().numpy()
     c_last, n_last = (enc >> 26) - 1, enc & ((1 << 26) - 1)
+    inside = np.zeros(Gx * Gy, bool); inside[ty0 * Gx:ty1 * Gx] = True
     for c in range(fr.plan.chunks_run):
         d = np.zeros((Gy * 16, Gx * 16), np.int64)
         d[:H, :W] = np.where(c_last == c, n_last, 0)
         want = d.reshape(Gy, 16, Gx, 16).max(axis=(1, 3)).reshape(-1)
         got = np.where(lens[c] > 0, walk[c], 0)
-        inside = np.zeros(Gx * Gy, bool); inside[ty0 * Gx:ty1 * Gx] = True
         if fr.plan.chunks_run == 1:
             np.testing.assert_array_equal(got[inside], want[inside])
         else:
             assert np.all(got[inside] >= want[inside])
-    nseg = np.where(lens > 0, np.maximum((walk + SEG - 1) // SEG, 1), 0)
-    nseg[:, :ty0 * Gx] = 0; nseg[:, ty1 * Gx:] = 0
+    nseg = np.where(lens > 0, (walk + SEG - 1) // SEG, 0)
+    nseg[:, ~inside] = 0
+    n_units = int(counts.sum())
     assert n_units == int(nseg.sum()) and n_units > 0
-    seen = set(zip(chunk.tolist(), tile.tolist(), seg.tolist()))
-    assert len(seen) == n_units                                               # no unit twice
-    assert np.all(seg < nseg[chunk, tile])                                    # ... and none outside its pair: so every one exactly once
-    np.testing.assert_array_equal(last, (seg == nseg[chunk, tile] - 1).astype(np.int64))
-    length = np.minimum(walk[chunk, tile] - seg * SEG, SEG)
-    assert np.all(length[1:] <= length[:-1]) and length.max() > 0
+    seen = set()
+    cap_full, cap_part = v["bwd_unit_caps"]
+    for sh in range(8):
+        for cls in range(17):
+            begin = 0 if cls == 0 else cap_full + (cls - 1) * cap_part
+            u = lists[sh, begin:begin + counts[sh, cls]]
+            tile, chunk, seg = u[:, 0] & ((1 << 24) - 1), u[:, 0] >> 24, u[:, 1]
+            assert np.all((tile - ty0 * Gx) % 8 == sh) and np.all(seg < nseg[chunk, tile])
+            length = np.minimum(walk[chunk, tile] - seg * SEG, SEG)           # full segments, then the partial ones by length class
+            step = SEG // 16
+            lo, hi = (SEG, SEG) if cls == 0 else (max((16 - cls) * step, 1), (17 - cls) * step - 1)
+            assert np.all((length >= lo) & (length <= hi)), (sh, cls)
+            seen |= set(zip(chunk.tolist(), tile.tolist(), seg.tolist()))
+    assert len(seen) == n_units                                               # none twice, none outside its pair: every one exactly once
     return n_units
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,H,P,rows", [(320, 208, 6000, None), (320, 208, 6000, (3, 9)), (2560, 1616, 40_000, None),
                                         (480, 320, 260_000, None)])
-def test_backward_work_units_cover_every_walked_entry_once_longest_first(W, H, P, rows):
-    """K7 runs one wave per (tile, chunk, segment) unit (csrc/gsr_bwd_units.h).  The last case is the frame with an uncovered
+def test_backward_work_units_cover_every_walked_entry_once(W, H, P, rows):
+    """K7 runs one wave per (tile, chunk, segment) unit, appended by the forward's waves (csrc/gsr_render.hip).  The last case is the frame with an uncovered
     half of test_frame_with_an_uncovered_region_...: several chunks, chunk-start checkpoints."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _native as N
@@ -1375,11 +1381,11 @@ def test_backward_work_units_cover_every_walked_entry_once_longest_first(W, H, P
 
 
 @pytest.mark.gpu
-def test_zero_fill_carries_the_backward_unit_list():
+def test_early_fill_clears_the_row_flags_and_gradients_are_bitwise_those_of_the_plain_path():
     """A training frame (gradients wanted, sparse geometry backward, binning workspace guessed from the previous frame) runs as
-    ONE gsr_forward whose zero fill also builds K7's unit list (k_zero_segments<true>, block 0): plan.tile_order_ready is set,
-    gsr_backward_render launches no k_bwd_units, the list is valid and the screen-space gradients equal, bit for bit, those of
-    the same frame run without the early fill (its own k_bwd_units launch)."""
+    ONE gsr_forward whose zero fill also clears the blend backward's row-valid flags (plan.tile_order_ready): the unit lists are
+    valid and the screen-space gradients equal, bit for bit, those of the same frame run without the early fill (memset in
+    gsr_backward_render)."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _native as N
     W, H, P = 640, 368, 200_000
@@ -1390,20 +1396,14 @@ def test_zero_fill_carries_the_backward_unit_list():
     needs = (True, True, True, False, True, True, True, False)
     g = S.make_grad_image(W, H, 6).to(DEV)
     _, _, plain = dgr.rasterize_forward(*args)                                    # also leaves the workspace guess behind
-    N.profile_enable(True)
     want = dgr.rasterize_backward_screen(plain, g).clone()
-    torch.cuda.synchronize()
-    prof = N.profile_read(); N.profile_enable(False)
-    assert plain.plan.tile_order_ready == 0 and "bwd_units" in prof
+    assert plain.plan.tile_order_ready == 0
     _, _, fr = dgr.rasterize_forward(*args, prepare_needs=needs)
-    assert int(fr.plan.chunk_rank_begin[fr.plan.chunks_run]) * 4 < P, "the scene must take the sparse path"
+    assert N.effective_binned_ranks(fr.plan) * 4 < P, "the scene must take the sparse path"
     assert fr.pre is not None and fr.pre["grads"].prezeroed == 1 and fr.plan.tile_order_ready == 1
     dgr.prepare_backward(fr, needs, screen_prefix_only=True)
-    N.profile_enable(True)
     got = dgr.rasterize_backward_screen(fr, g)
     torch.cuda.synchronize()
-    prof = N.profile_read(); N.profile_enable(False)
-    assert "render_bwd" in prof and "bwd_units" not in prof, sorted(prof)
     v = N.debug_views(fr.desc, fr.geom_ws, fr.binning_ws, fr.image_ws, fr.plan)
     _check_bwd_units(fr, v, W, H, None)
     n_pref = int(fr.plan.chunk_rank_begin[fr.plan.chunks_run])
