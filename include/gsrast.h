@@ -314,6 +314,19 @@ int gsr_adam_step_split(int64_t rows, int32_t row_len, int32_t split, float *par
                         float *exp_avg_sq, float lr_head, float lr_tail, float beta1, float beta2, float eps, int64_t step,
                         void *stream);
 
+/* The whole optimizer step in ONE launch: up to GSR_ADAM_MAX_TENSORS tensors, each with its own learning rate(s) and step
+ * count (the reference's six groups: five tensors here, the SH table with split rows).  tensors: HOST array.  Element for
+ * element what the per-tensor calls compute. */
+#define GSR_ADAM_MAX_TENSORS 8
+typedef struct gsr_adam_tensor {
+    float *param; const float *grad; float *exp_avg; float *exp_avg_sq;
+    int64_t n;                  /* elements */
+    float lr, lr_tail;          /* lr_tail: for elements [split, row_len) of every row (row_len > 0) */
+    int64_t step;               /* this tensor's step count (>= 1), for the bias corrections */
+    int32_t row_len, split;     /* row_len == 0: one learning rate for the whole tensor */
+} gsr_adam_tensor;
+int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor *tensors, float beta1, float beta2, float eps, void *stream);
+
 /* ---- the activations between the optimizer's raw parameters and the rasterizer's inputs, the
  * getters of scene/gaussian_model.py:101-125 (setup_functions :47-60):
  *   scales [P,3] = exp(scaling_raw)   rotations [P,4] = rotation_raw / max(|rotation_raw|_2, 1e-12)   opacities [P] = sigmoid(opacity_raw)

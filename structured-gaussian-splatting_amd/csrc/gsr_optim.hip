@@ -48,6 +48,71 @@ __global__ __launch_bounds__(kAdamBlock) void k_adam(size_t n, float *__restrict
 #undef GSR_ADAM1
 }
 
+// ---- every tensor of the optimizer in one launch.  Work item = kMultiChunk consecutive float4 of one tensor (a block walks
+// items blockIdx.x, + gridDim.x, ...; each thread takes kMultiPer float4 of the item 256 apart: all of a thread's 4 kMultiPer
+// loads are issued before the first store).  Five launches of the one-tensor kernel left four kernel boundaries and four tails
+// in a 0.35 ms step.
+constexpr int kMultiPer = 4;
+constexpr int kMultiChunk = kAdamBlock * kMultiPer;          // float4 per work item
+struct AdamMulti {
+    float *p[GSR_ADAM_MAX_TENSORS]; const float *g[GSR_ADAM_MAX_TENSORS]; float *m[GSR_ADAM_MAX_TENSORS]; float *v[GSR_ADAM_MAX_TENSORS];
+    unsigned long long n[GSR_ADAM_MAX_TENSORS];
+    unsigned long long item_end[GSR_ADAM_MAX_TENSORS];       // running count of work items
+    float step_head[GSR_ADAM_MAX_TENSORS], step_tail[GSR_ADAM_MAX_TENSORS], inv_bc2_sqrt[GSR_ADAM_MAX_TENSORS];
+    uint32_t row_len[GSR_ADAM_MAX_TENSORS], split[GSR_ADAM_MAX_TENSORS];
+    int count;
+};
+
+__global__ __launch_bounds__(kAdamBlock) void k_adam_multi(AdamMulti a, float one_minus_b1, float b2, float one_minus_b2, float eps)
+{
+    const unsigned long long items = a.item_end[a.count - 1];
+    for (unsigned long long it = blockIdx.x; it < items; it += gridDim.x) {
+        int t = 0;
+        while (it >= a.item_end[t]) ++t;                               // block-uniform, <= 8 steps
+        const unsigned long long first = (it - (t ? a.item_end[t - 1] : 0ull)) * kMultiChunk;      // float4 index inside tensor t
+        const unsigned long long n = a.n[t], n4 = n / 4;
+        float4 *p4 = reinterpret_cast<float4 *>(a.p[t]), *m4 = reinterpret_cast<float4 *>(a.m[t]), *v4 = reinterpret_cast<float4 *>(a.v[t]);
+        const float4 *g4 = reinterpret_cast<const float4 *>(a.g[t]);
+        const float sh = a.step_head[t], stl = a.step_tail[t], ib = a.inv_bc2_sqrt[t];
+        const uint32_t row_len = a.row_len[t], split = a.split[t];
+        float4 pp[kMultiPer], mm[kMultiPer], vv[kMultiPer], gg[kMultiPer];
+#pragma unroll
+        for (int k = 0; k < kMultiPer; ++k) {
+            const unsigned long long i = first + threadIdx.x + (unsigned long long)k * kAdamBlock;
+            if (i < n4) { pp[k] = p4[i]; mm[k] = m4[i]; vv[k] = v4[i]; gg[k] = g4[i]; }
+        }
+#pragma unroll
+        for (int k = 0; k < kMultiPer; ++k) {
+            const unsigned long long i = first + threadIdx.x + (unsigned long long)k * kAdamBlock;
+            if (i >= n4) continue;
+            float4 st = make_float4(sh, sh, sh, sh);
+            if (row_len) {
+                const uint32_t col = (uint32_t)((i * 4) % row_len);
+                auto pick = [&](uint32_t c) { c = c >= row_len ? c - row_len : c; return c < split ? sh : stl; };
+                st = make_float4(pick(col), pick(col + 1), pick(col + 2), pick(col + 3));
+            }
+#define GSR_ADAM1(c)                                                                      \
+            mm[k].c = mm[k].c + (gg[k].c - mm[k].c) * one_minus_b1;                       \
+            vv[k].c = vv[k].c * b2 + one_minus_b2 * gg[k].c * gg[k].c;                    \
+            pp[k].c = pp[k].c - st.c * (mm[k].c / (sqrtf(vv[k].c) * ib + eps));
+            GSR_ADAM1(x) GSR_ADAM1(y) GSR_ADAM1(z) GSR_ADAM1(w)
+#undef GSR_ADAM1
+            p4[i] = pp[k]; m4[i] = mm[k]; v4[i] = vv[k];
+        }
+        // the tensor's last item also takes the n % 4 trailing elements
+        if (first <= n4 && first + kMultiChunk > n4 && threadIdx.x < (unsigned)(n - n4 * 4)) {
+            const unsigned long long i = n4 * 4 + threadIdx.x;
+            float m1 = a.m[t][i], v1 = a.v[t][i];
+            const float g1 = a.g[t][i];
+            m1 = m1 + (g1 - m1) * one_minus_b1;
+            v1 = v1 * b2 + one_minus_b2 * g1 * g1;
+            const float st = row_len && (uint32_t)(i % row_len) >= split ? stl : sh;
+            a.p[t][i] = a.p[t][i] - st * (m1 / (sqrtf(v1) * ib + eps));
+            a.m[t][i] = m1; a.v[t][i] = v1;
+        }
+    }
+}
+
 // ---- densification bookkeeping of one training iteration (train.py:127-130 + scene/gaussian_model.py:415-417):
 //   max_radii2D[vis] = max(max_radii2D[vis], radii[vis]);  xyz_gradient_accum[vis] += |viewspace grad.xy|;  denom[vis] += 1
 // with vis = radii > 0.  One pass and no host synchronisation, where boolean-mask indexing costs four nonzero()
@@ -126,6 +191,44 @@ extern "C" int gsr_adam_step_split(int64_t rows, int32_t row_len, int32_t split,
     ProfileScope prof("adam", s);
     hipLaunchKernelGGL(k_adam<true>, dim3((unsigned)blocks), dim3(kAdamBlock), 0, s, n, param, grad, exp_avg, exp_avg_sq, 1.f - beta1, beta2,
                        1.f - beta2, step_head, inv_bc2_sqrt, eps, (uint32_t)row_len, (uint32_t)split, step_tail);
+    GSR_LAUNCH_CHECK("adam", false, s);
+    return GSR_OK;
+}
+
+extern "C" int gsr_adam_step_multi(int32_t count, const gsr_adam_tensor *tensors, float beta1, float beta2, float eps, void *stream)
+{
+    if (count < 0 || count > GSR_ADAM_MAX_TENSORS || (count > 0 && !tensors)) {
+        set_error("gsr_adam_step_multi: 0 .. %d tensors", GSR_ADAM_MAX_TENSORS);
+        return GSR_ERR_INVALID_ARGUMENT;
+    }
+    AdamMulti a;
+    a.count = 0;
+    unsigned long long items = 0;
+    for (int i = 0; i < count; ++i) {
+        const gsr_adam_tensor &t = tensors[i];
+        if (t.n < 0 || t.step < 1 || (t.n > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) ||
+            (t.row_len != 0 && (t.row_len < 4 || t.split < 0 || t.split > t.row_len || t.n % t.row_len != 0))) {
+            set_error("gsr_adam_step_multi: bad tensor %d (row_len 0 or >= 4 and dividing n, 0 <= split <= row_len, step >= 1)", i);
+            return GSR_ERR_INVALID_ARGUMENT;
+        }
+        if (t.n == 0) continue;
+        const int k = a.count++;
+        const double bc1 = 1.0 - pow((double)beta1, (double)t.step), bc2 = 1.0 - pow((double)beta2, (double)t.step);
+        a.p[k] = t.param; a.g[k] = t.grad; a.m[k] = t.exp_avg; a.v[k] = t.exp_avg_sq;
+        a.n[k] = (unsigned long long)t.n;
+        a.step_head[k] = (float)((double)t.lr / bc1); a.step_tail[k] = (float)((double)t.lr_tail / bc1);
+        a.inv_bc2_sqrt[k] = (float)(1.0 / sqrt(bc2));
+        a.row_len[k] = (uint32_t)t.row_len; a.split[k] = (uint32_t)t.split;
+        items += ((unsigned long long)t.n / 4 + kMultiChunk - 1) / kMultiChunk;
+        if (((unsigned long long)t.n / 4) % kMultiChunk == 0 && t.n % 4 != 0) items += 1;      // an item for the trailing elements alone
+        a.item_end[k] = items;
+    }
+    if (a.count == 0) return GSR_OK;
+    for (int k = a.count; k < GSR_ADAM_MAX_TENSORS; ++k) { a.item_end[k] = items; a.n[k] = 0; a.p[k] = nullptr; a.g[k] = nullptr; a.m[k] = nullptr; a.v[k] = nullptr; }
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long blocks = items < 16384 ? items : 16384;
+    ProfileScope prof("adam", s);
+    hipLaunchKernelGGL(k_adam_multi, dim3((unsigned)blocks), dim3(kAdamBlock), 0, s, a, 1.f - beta1, beta2, 1.f - beta2, eps);
     GSR_LAUNCH_CHECK("adam", false, s);
     return GSR_OK;
 }

@@ -66,7 +66,7 @@ class DebugViews(C.Structure):
 EXPORTS = ("gsr_version", "gsr_last_error", "gsr_workspace_sizes", "gsr_binning_size", "gsr_binning_first_chunk_capacity", "gsr_forward_preprocess", "gsr_forward",
            "gsr_forward_render", "gsr_bwd_segment_entries", "gsr_backward_rows_size", "gsr_backward_prepare", "gsr_backward_render", "gsr_backward_geom", "gsr_backward_geom_rows", "gsr_frame_arrays", "gsr_exchange_rows_gather", "gsr_exchange_rows_scatter", "gsr_mark_visible", "gsr_debug_get_views", "gsr_profile_enable",
            "gsr_profile_read", "gsr_loss_workspace_size", "gsr_loss_l1_ssim_forward", "gsr_loss_l1_ssim_backward", "gsr_loss_l1_ssim_forward_rows", "gsr_loss_l1_ssim_backward_rows", "gsr_loss_l1_backward",
-           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_adam_step_split", "gsr_densify_stats",
+           "gsr_debug_sort_temp_bytes", "gsr_debug_sort_pairs", "gsr_dist2_workspace_size", "gsr_dist2_knn3", "gsr_adam_step", "gsr_adam_step_split", "gsr_adam_step_multi", "gsr_densify_stats",
            "gsr_activations_forward", "gsr_activations_backward")
 
 _lib = None
@@ -396,6 +396,25 @@ def adam_step_split(param, grad, exp_avg, exp_avg_sq, split, lr_head, lr_tail, b
     _check(load().gsr_adam_step_split(C.c_int64(rows), C.c_int32(row_len), C.c_int32(int(split)), _ptr(param), _ptr(grad), _ptr(exp_avg),
                                       _ptr(exp_avg_sq), C.c_float(lr_head), C.c_float(lr_tail), C.c_float(beta1), C.c_float(beta2),
                                       C.c_float(eps), C.c_int64(int(step)), _stream(param.device)), "gsr_adam_step_split")
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("n", C.c_int64),
+                ("lr", C.c_float), ("lr_tail", C.c_float), ("step", C.c_int64), ("row_len", C.c_int32), ("split", C.c_int32)]
+
+
+ADAM_MAX_TENSORS = 8
+
+
+def adam_step_multi(items, beta1, beta2, eps):
+    """items: up to ADAM_MAX_TENSORS tuples (param, grad, exp_avg, exp_avg_sq, lr, lr_tail, step, row_len, split) — the whole
+    optimizer step in one launch (row_len = 0: one learning rate for the tensor)."""
+    arr = (AdamTensor * len(items))()
+    for a, (p, g, m, v, lr, lr_tail, step, row_len, split) in zip(arr, items):
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.n = _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel()
+        a.lr, a.lr_tail, a.step, a.row_len, a.split = float(lr), float(lr_tail), int(step), int(row_len), int(split)
+    _check(load().gsr_adam_step_multi(C.c_int32(len(items)), arr, C.c_float(beta1), C.c_float(beta2), C.c_float(eps),
+                                      _stream(items[0][0].device)), "gsr_adam_step_multi")
 
 
 def activations_forward(scaling_raw, rotation_raw, opacity_raw):

@@ -46,6 +46,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        batch = []          # native tensors of this step: ONE launch for all of them (groups that share betas and eps: the reference's do)
         for group in self.param_groups:
             b1, b2 = group["betas"]
             head_cols = group.get("head_cols") if group.get("tail") else None
@@ -68,15 +69,23 @@ class FusedAdam(torch.optim.Optimizer):
                     self._torch_step(p, p.grad, st, (lr / bc1, None if lr_tail is None else lr_tail / bc1), b1, b2, group["eps"], step,
                                      head_cols)
                     continue
-                from diff_gaussian_rasterization import _native as N
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                with torch.cuda.device(p.device):
-                    if head_cols is None or p.shape[1] <= head_cols:
-                        N.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], lr, b1, b2, group["eps"], step)
-                    else:
-                        per_col = p.numel() // max(p.shape[0] * p.shape[1], 1)
-                        N.adam_step_split(p, g, st["exp_avg"], st["exp_avg_sq"], head_cols * per_col, lr, lr_tail, b1, b2, group["eps"],
-                                          step)
-                torch.autograd.graph.increment_version(p)    # the kernel wrote through the raw pointer: tell autograd (and the
-                                                             # model's activation cache, which keys on versions)
+                if head_cols is None or p.shape[1] <= head_cols:
+                    item = (p, g, st["exp_avg"], st["exp_avg_sq"], lr, lr, step, 0, 0)
+                else:
+                    per_col = p.numel() // max(p.shape[0] * p.shape[1], 1)
+                    item = (p, g, st["exp_avg"], st["exp_avg_sq"], lr, lr_tail, step, p.numel() // max(p.shape[0], 1), head_cols * per_col)
+                batch.append(((b1, b2, group["eps"], p.device), item))
+        if batch:
+            from diff_gaussian_rasterization import _native as N
+            while batch:
+                key = batch[0][0]
+                now = [it for k, it in batch if k == key][:N.ADAM_MAX_TENSORS]
+                taken = {id(it[0]) for it in now}
+                batch = [(k, it) for k, it in batch if id(it[0]) not in taken]
+                with torch.cuda.device(key[3]):
+                    N.adam_step_multi(now, key[0], key[1], key[2])
+                for it in now:
+                    torch.autograd.graph.increment_version(it[0])    # the kernel wrote through the raw pointer: tell autograd (and
+                                                                     # the model's activation cache, which keys on versions)
         return loss
