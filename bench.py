@@ -13,7 +13,7 @@ starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself 
 
 Prints ONE JSON line on rank 0.  Besides the contract's keys:
   roofline      dominant kernel of the step, timed live with hipEvents inside libgsrast.so; `valu` prices the blend
-                kernel's measured instruction mix (profiles/r02_valu_mix.json) with the issue rates measured by
+                kernel's measured instruction mix (profiles/r03_valu_mix.json) with the issue rates measured by
                 profiles/valu_microbench on this chip
   cpu_baseline  the CPU oracle (a port, test infrastructure) on rank 0 at N = 1 only; .cfg1 = BASELINE configs[0]
   secondary     the same step on a NON-saturating scene (scene_synth CONFIGS["cfg3n"]: R/P = 3.6, 98 % of the visible
@@ -64,7 +64,7 @@ def _set_affinity_all_threads(cpus):
             pass
 
 
-def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, C=3):
+def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, C=3, walked=None, units=0):
     """ALGORITHMIC bytes per step and kernel: SURVEY.md 8d's per-unit figures x the units each kernel processes in THIS
     design.  P Gaussians, V visible, Vb = Gaussians of the depth chunks that were binned (the
     depth prefix), Re = instances actually emitted by the progressive binning (the reference would process R =
@@ -72,6 +72,7 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
     array is charged once per read and once per write, to the kernel that moves it: zero rows are charged to
     `zero_outputs` when the early fill runs (then NOT to geom_bwd), SH coefficients to `chunk_colors` (the lazy colour
     pass reads them for binned Gaussians only), never to `preprocess`."""
+    walked = Re if walked is None else walked               # list entries in front of their tile's deepest contributor: what K7 walks
     geom_rows = Vb if sparse_geom else P                    # rows the geometry backward visits
     geom_written = Vlive if prezeroed else geom_rows        # after an early fill only live rows are written
     return {
@@ -93,10 +94,13 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
         # a14: exp / normalize / sigmoid of (3 + 4 + 1) floats per Gaussian: 32 in + 32 out; backward reads the 8 incoming
         # gradients, the saved outputs / raw quaternion (8) and writes 8
         "activations_fwd": 64 * P, "activations_bwd": 96 * P,
-        "render_fwd": 40 * Re + 20 * N + 4 * Tn,            # K6: id 4 + record 36 per instance; 20 B/px; per tile its walked depth out
-        "render_bwd": 76 * Re + 20 * N + 4 * Tn,            # K7: 40 read + 36 written per instance; 20 B/px; its tile from the launch order
-        "bwd_units": 12 * Tn,                               # K7 work units (gsr_bwd_units.h): ranges + walked depth in, units out
-        "reduce_rows": 36 * Re + 36 * Vb,                   # deterministic reduction (replaces atomic RMW)
+        # K6: id 4 + record 36 per instance; 20 B/px; per tile its walked depth and its work units out; one 4 KB checkpoint per
+        # kSeg = 128 walked entries (32 B per walked instance)
+        "render_fwd": 40 * Re + 20 * N + 12 * Tn + 32 * walked,
+        # K7 (front to back, one wave per work unit): 40 read + 36 written per walked instance (an upper bound for the rows: only
+        # splats some pixel accepts are written); per unit the 256 pixels' 32 B (T, last, dL/dpix, final colour) + its 16 B/px checkpoint
+        "render_bwd": 76 * walked + 256 * 48 * units,
+        "reduce_rows": Re + 36 * walked + 36 * Vb,          # deterministic reduction (replaces atomic RMW): a valid byte per row, written rows only
         "geom_bwd": 4 * geom_rows + (99 + 12 * K) * Vlive + (40 + 12 * M) * geom_written,        # K8 + K9
         "loss_fwd": 20 * C * N, "loss_bwd": 24 * C * N,
         "zero_outputs": (56 + 12 * M) * P if prezeroed else 0,       # early fill of the parameter gradients (means3D, means2D, opacity,
@@ -389,8 +393,8 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
     stats = _frame_stats(model, cam, bg, pipe)
     R, Re, Vlive, pairs = stats["num_rendered"], stats["emitted"], stats["live"], stats["pairs_bwd"]
     Vb = stats["binned_ranks"]
-    sparse = Vb * 4 < P
-    alg = algorithmic_bytes(P, V, Vb, Re, Npix, Tn, K, M, Vlive, sparse_geom=sparse, prezeroed=sparse)
+    sparse = N.effective_binned_ranks(stats["plan"]) * 4 < P
+    alg = algorithmic_bytes(P, V, Vb, Re, Npix, Tn, K, M, Vlive, sparse_geom=sparse, prezeroed=sparse, walked=stats["walked"], units=stats["units"])
     per_kernel = {}
     for k, (ms, n) in prof.items():
         per_step_ms = ms / steps
@@ -421,7 +425,7 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
                         # (all R = num_rendered duplicates; this design bins `instances_emitted` of them), over the same time
                         reference_formula_step_bytes=int(ref_bytes),
                         reference_formula_step_frac=round(ref_bytes / 1e9 / (elapsed / steps) / HBM_PEAK_GBS, 5),
-                        valu=_valu_roofline(dom, dom_ms, workload) if traffic else None,
+                        valu=_valu_roofline(dom, dom_ms, workload) if (traffic or workload == "cfg3n") else None,
                         pairs_per_s_G=round(pairs / 1e9 / (bwd_ms / 1e3), 1) if bwd_ms > 0 else None,
                         note="the blend kernels are VALU-issue-bound, not HBM-bound (SURVEY 8d caveat): `valu` is their "
                              "roofline; pairs_per_s_G = (pixel, splat) pairs per second in render_bwd")
@@ -433,6 +437,7 @@ def measure(workload, steps, warmup, ctx, extras, traffic, profile=True):
                                + "); step = render() + L1/D-SSIM loss + backward (train.py:79-108 window)",
                    "visible": V, "num_rendered": R, "instances_emitted": Re, "chunks_run": stats["chunks_run"],
                    "chunks_planned": stats["chunks_planned"], "binned_gaussians": Vb, "gaussians_with_gradient": Vlive,
+                   "instances_walked_bwd": stats["walked"], "bwd_work_units": stats["units"],
                    "emitted_over_num_rendered": round(Re / max(R, 1), 4)},
         "raster_ms_per_step": round(raster_ms, 4), "profiled_ms_per_step": round(1e3 * elapsed_profiled / steps, 4),
         "gc_in_timed_window": gc_headline,
@@ -496,9 +501,11 @@ def _frame_stats(model, cam, bg, pipe):
         g = torch.ones(3, H, W, device=enc.device)
         screen = dgr.rasterize_backward_screen(fr, g)
         live = int((screen.abs().sum(1) > 0).sum())
+        walked = int(torch.minimum(v["tile_walk"].long()[:fr.plan.chunks_run], lens).sum())
+        units = int(v["bwd_unit_count"].long().sum())
         binned = int(fr.plan.chunk_rank_begin[fr.plan.chunks_run]) if fr.plan.num_rendered > 0 and fr.plan.chunks_run > 0 else 0
     return dict(num_rendered=fr.R, emitted=emitted, chunks_run=int(fr.plan.chunks_run), chunks_planned=int(fr.plan.num_chunks),
-                live=live, pairs_bwd=int(ncontrib.sum()), binned_ranks=binned)
+                live=live, pairs_bwd=int(ncontrib.sum()), binned_ranks=binned, walked=walked, units=units, plan=fr.plan)
 
 
 def _train_loop(workload, iters, dev, native_getters):
@@ -581,14 +588,15 @@ def _traffic_from_profiles(kernel):
 
 def _valu_roofline(kernel, launch_ms, workload):
     """VALU-issue roofline of the dominant (blend) kernel.  Inputs, both committed under profiles/ and measured on MI355X:
-      * valu_microbench/r02_valu_rates.json — issue cycles one wave64 instruction of each class costs its SIMD at
+      * valu_microbench/r03_valu_rates.json — issue cycles one wave64 instruction of each class costs its SIMD at
         saturation (profiles/valu_microbench/valu_microbench.hip: v_mul/add 2.2, v_fma 3.6, packed fp32 / compares /
         selects / min / max / DPP 4.1-4.2, transcendentals 8.1 cycles);
-      * r02_valu_mix.json — for the default cfg3 run: the kernel's VALU wave-instructions per launch by class (rocprofv3
+      * r03_valu_mix.json (r03_cfg3n_valu_mix.json for the secondary workload) — for the default cfg3 run: the kernel's VALU wave-instructions per launch by class (rocprofv3
         PMC SQ_INSTS_VALU_* + the packed share of each class from the disassembly), made by profiles/valu_mix.py.
     required = sum over classes of instructions x issue cycles; available = SIMDs x cycles of the launch.
     `frac` = required / available: 1.0 would mean every SIMD issues a VALU instruction on every cycle of the launch."""
-    rates, mix = _profiles_json("valu_microbench/r02_valu_rates.json"), _profiles_json("r02_valu_mix.json")
+    rates = _profiles_json("valu_microbench/r03_valu_rates.json") or _profiles_json("valu_microbench/r02_valu_rates.json")
+    mix = _profiles_json("r03_cfg3n_valu_mix.json" if workload == "cfg3n" else "r03_valu_mix.json")
     if not rates or not mix or kernel not in mix.get("kernels", {}) or mix.get("workload", "cfg3") != workload:
         return None
     k = mix["kernels"][kernel]

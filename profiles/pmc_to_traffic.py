@@ -27,7 +27,9 @@ NAMES = {
     "void gsr::k_bin_chunk<true>": "emit", "gsr::k_ranges": "ranges", "gsr::k_tile_gather": "tile_gather",
     "gsr::k_tile_ranges": "tile_ranges", "void gsr::k_sel_hist<": "depth_hist", "gsr::k_part_count": "depth_partition",
     "gsr::k_part_scatter": "depth_partition", "gsr::k_chunk_sort_small": "chunk_sort", "gsr::k_zero_segments": "zero_outputs",
-    "gsr::k_act_fwd": "activations_fwd", "gsr::k_act_bwd": "activations_bwd", "void gsr::k_tile_order<": "tile_order",
+    "gsr::k_act_fwd": "activations_fwd", "gsr::k_act_bwd": "activations_bwd", "void gsr::k_chunk_colors_all<": "chunk_colors",
+    "void gsr::k_chunk_colors<": "chunk_colors", "void gsr::k_radix_hist<": "radix", "gsr::k_radix_scan": "radix", "void gsr::k_radix_scatter": "radix",
+    "gsr::k_adam_multi": "adam", "void gsr::k_adam<": "adam",
 }
 SKIP_FIRST = 3
 
@@ -47,6 +49,9 @@ def per_launch(path, counter):
 
 def main():
     fetch_csv, write_csv, outdir = sys.argv[1:4]
+    # optional: <traffic file name> <detail file name> (defaults: the cfg3 files bench.py reads)
+    traffic_name = sys.argv[4] if len(sys.argv) > 4 else "traffic.json"
+    detail_name = sys.argv[5] if len(sys.argv) > 5 else "r03_pmc_traffic_detail.json"
     fetch, write = per_launch(fetch_csv, "FETCH_SIZE"), per_launch(write_csv, "WRITE_SIZE")
     detail, traffic = {}, {}
     for k in sorted(set(fetch) & set(write)):
@@ -55,9 +60,9 @@ def main():
         detail[k] = dict(fetch_bytes_per_launch=int(fb), write_bytes_per_launch=int(wb), hbm_bytes_per_launch=int(fb + wb),
                          launches_sampled=min(len(fetch[k]), len(write[k])))
         traffic[k] = int(fb + wb)
-    with open(os.path.join(outdir, "traffic.json"), "w") as f:
+    with open(os.path.join(outdir, traffic_name), "w") as f:
         json.dump(traffic, f, indent=1)
-    with open(os.path.join(outdir, "r02_pmc_traffic_detail.json"), "w") as f:
+    with open(os.path.join(outdir, detail_name), "w") as f:
         json.dump(detail, f, indent=1)
     print(json.dumps(detail, indent=1))
 

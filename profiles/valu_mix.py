@@ -23,6 +23,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = {"gsr::k_render_bwd": "render_bwd", "gsr::k_render_fwd": "render_fwd"}
+WORKLOAD = "cfg3"
 SKIP_FIRST = 3
 
 
@@ -58,7 +59,7 @@ def isa_counts(path):
             t = line.strip().split()
             if t and t[0].startswith("v_"):
                 mn = t[0]
-                if ("row_shr" in line or "row_bcast" in line or "quad_perm" in line) and not mn.endswith("_dpp"):
+                if ("row_shr" in line or "row_bcast" in line or "quad_perm" in line or "row_ror" in line or "row_half_mirror" in line or "row_shl" in line) and not mn.endswith("_dpp"):
                     mn += "_dpp"
                 out[cur][mn] += 1
     return out
@@ -72,7 +73,7 @@ def mix(pmc_csv, isa_path, out_path):
                 if row["Kernel_Name"].startswith(prefix):
                     per[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
     isa = isa_counts(isa_path)
-    out = {"workload": "cfg3", "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 "
+    out = {"workload": WORKLOAD, "source": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 "
            "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SALU -- python3 bench.py --steps 6 --warmup 2 "
            "--no-cpu-baseline --no-secondary", "kernels": {}}
     for key, ctr in per.items():
@@ -96,7 +97,7 @@ def mix(pmc_csv, isa_path, out_path):
         movs = sum(c for m, c in n.items() if m.startswith("v_mov") or m.startswith("v_accvgpr"))
         others_static = sum(c for m, c in n.items() if re.match(r"v_(cmp|cndmask|min|max|med3|mov|readlane|readfirstlane|and|or|lshl|bfe|add_f32_dpp)", m)) or 1
         s_mov = min(movs / others_static, 1.0)
-        perm = sum(c for m, c in n.items() if m.startswith("v_permlane32_swap"))       # two-splat wave reduction (round 2): 8.2 cycles
+        perm = sum(c for m, c in n.items() if m.startswith("v_permlane32_swap") or m.startswith("v_permlane16_swap"))       # the butterfly reduction's swaps: 8.2 cycles
         s_perm = min(perm / (others_static + perm), 1.0)
         counts = {
             "v_pk_fma_f32": fma * s_fma, "v_fma_f32": fma * (1 - s_fma), "v_pk_mul_f32": mul * s_mul, "v_mul_f32": mul * (1 - s_mul),
@@ -116,4 +117,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "rates":
         rates(sys.argv[2], sys.argv[3])
     else:
+        if len(sys.argv) > 5:
+            WORKLOAD = sys.argv[5]
         mix(sys.argv[2], sys.argv[3], sys.argv[4])
