@@ -373,7 +373,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         BinningWS bw0 = carve_binning(binning_ws, 0, f);
         if (f.P == 0 || !geom_ws) gw0.ctrl = iw.ctrl_scratch;   // no geometry workspace at all
         if ((rc = launch_binning_init(f, gw0, iw, dbg, s))) return rc;
-        if ((rc = launch_render_fwd(f, *cam, 0, true, gw0, bw0, iw, out_color, dbg, s))) return rc;
+        if ((rc = launch_render_fwd(f, *cam, 0, true, 0, gw0, bw0, iw, out_color, dbg, s))) return rc;
         plan->chunks_run = 1;
         return GSR_OK;
     }
@@ -451,7 +451,7 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
                                        (plan->chunks_filtered >> c) & 1)))
             return rc;
         if ((rc = launch_chunk_colors(f, *cam, *g, r0, r1, plan->num_visible, gw, dbg, s))) return rc;      // A.6 for this chunk's Gaussians only
-        if ((rc = launch_render_fwd(f, *cam, c, last, gw, bw, iw, out_color, dbg, s))) return rc;
+        if ((rc = launch_render_fwd(f, *cam, c, last, sort_result, gw, bw, iw, out_color, dbg, s))) return rc;
         plan->chunks_run = c + 1;
         plan->instances_emitted = -1;                 // the last chunk's count stays on the device
         if (last) break;
@@ -704,7 +704,7 @@ int gsr_debug_get_views(const gsr_frame_desc *desc, const void *geom_ws, const v
     }
     if (binning_ws) {
         BinningWS bw = carve_binning(const_cast<void *>(binning_ws), plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered, f);
-        v->sorted_gaussian = bw.sorted_gid;
+        v->sorted_gaussian = bw.gids[1];
         v->bwd_units = reinterpret_cast<const uint32_t *>(bw.units.units); v->bwd_unit_cap_full = bw.units.cap_full; v->bwd_unit_cap_part = bw.units.cap_part;
     }
     if (image_ws) {

@@ -93,8 +93,7 @@ BinningWS carve_binning(void *base, int64_t R, const FrameK &f)
     const size_t Rn = (size_t)(R > 0 ? R : 1), Tn = (size_t)f.Gx * f.Gy;
     for (int i = 0; i < 2; ++i) { w.keys[i] = (uint32_t *)(b + o); o += align_up(Rn * 4); }
     for (int i = 0; i < 2; ++i) { w.vals[i] = (uint32_t *)(b + o); o += align_up(Rn * 4); }
-    w.inst_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
-    w.sorted_gid = (uint32_t *)(b + o); o += align_up(Rn * 4);
+    for (int i = 0; i < 2; ++i) { w.gids[i] = (uint32_t *)(b + o); o += align_up(Rn * 4); }
     w.row_valid = (uint8_t *)(b + o); o += align_up(Rn);
     w.ckpt = (float *)(b + o); o += align_up((Rn / kSeg + 2) * (size_t)kCkptFloats * sizeof(float));
     {
@@ -821,6 +820,9 @@ int launch_live_filter(const FrameK &f, int c, int r0, int r1, const LiveParts &
 }
 
 // ---- ranges of the chunk's sorted list (grid-stride, element count on the device)
+// GATHER: also sorted_gid[a] = inst_gid[slot at a] (sorts below 4 M instances, whose slot -> Gaussian table stays in the L2 / Infinity
+// Cache; above, the word travels through the radix passes as a second payload: the gather read 128 B per 4-byte word, 3.1 GB at 23 M)
+template <bool GATHER>
 __global__ __launch_bounds__(kBinBlock) void k_ranges(int c, const Ctrl *__restrict__ ctrl, const uint32_t *__restrict__ keys,
                                                       const uint32_t *__restrict__ slots, const uint32_t *__restrict__ inst_gid,
                                                       uint2 *__restrict__ ranges, uint32_t *__restrict__ sorted_gid)
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(kBinBlock) void k_ranges(int c, const Ctrl *__restr
             if (prev != tile) { ranges[prev].y = a; ranges[tile].x = a; }
         }
         if (i == n - 1) ranges[tile].y = a + 1;
-        sorted_gid[a] = inst_gid[slots[a]];
+        if constexpr (GATHER) sorted_gid[a] = inst_gid[slots[a]];
     }
 }
 
@@ -878,6 +880,12 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
     float4 *meta_b = reinterpret_cast<float4 *>(scratch + 4 * (size_t)n);
     uint32_t *wprefix = scratch + 8 * (size_t)n;
     const int tile_bits = msb_plus1((uint32_t)(Tn ? Tn - 1 : 0));
+    // The blend kernels find a sorted entry's Gaussian (| quadrant mask) in gids[1], always.  Large sorts carry the word through the
+    // radix passes (the emit kernels then write it into the buffer the passes leave in [1]); small ones gather it behind the sort.
+    const int sort_passes = ((tile_bits > 0 ? tile_bits : 1) + 7) / 8;
+    const bool carry_gid = n_max >= (4ull << 20);
+    uint32_t *const gid_emit = bw.gids[carry_gid && !(sort_passes & 1) ? 1 : 0];
+    uint32_t *const gid_pingpong[2] = {gid_emit, gid_emit == bw.gids[0] ? bw.gids[1] : bw.gids[0]};
     // a filtered chunk: a fixed grid walks the live front part; everybody else's count is zero from the start
     const int team_grid = filtered ? (n < 65536 ? n : 65536) : n;      // (4 k: +35 us per launch, 256 k: +20 us; measured)
     if (filtered) GSR_HIP_CHECK(hipMemsetAsync(gw.cnt_open + r0, 0, (size_t)n * sizeof(uint32_t), s));
@@ -888,7 +896,7 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
                        gw.offs_full, masks, gw.cnt_open, iw.tile_cnt, wprefix, meta_a, meta_b, n)
         if (flat)
             hipLaunchKernelGGL(k_bin_chunk<false>, dim3(bin_blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records,
-                               iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);
+                               iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], gid_emit, gw.row_begin);
         else if (team == 16) { if (gather) GSR_CT(16, true); else GSR_CT(16, false); }
         else if (team == 4) { if (gather) GSR_CT(4, true); else GSR_CT(4, false); }
         else { if (gather) GSR_CT(1, true); else GSR_CT(1, false); }
@@ -914,7 +922,7 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
         const uint64_t rank_blocks = ((uint64_t)n + kGatherBlock - 1) / kGatherBlock;
         const uint64_t blocks = tile_blocks > rank_blocks ? tile_blocks : rank_blocks;
         hipLaunchKernelGGL(k_tile_gather, dim3((unsigned)blocks), dim3(kGatherBlock), 0, s, f, c, r0, n, gw.ctrl, iw.ranges + (size_t)c * Tn,
-                           meta_a, meta_b, masks, wprefix, gw.cnt_open, gw.offs_open, bw.sorted_gid, bw.vals[res], gw.row_begin);
+                           meta_a, meta_b, masks, wprefix, gw.cnt_open, gw.offs_open, bw.gids[1], bw.vals[res], gw.row_begin);
         GSR_LAUNCH_CHECK("tile_gather", debug, s);
         return GSR_OK;
     }
@@ -922,10 +930,10 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
         ProfileScope prof("emit", s);
 #define GSR_ET(W)                                                                                                          \
     hipLaunchKernelGGL(k_emit_team<W>, dim3(team_grid), dim3(W * kWave), 0, s, f, c, r0, gw.order, gw.records, gw.ctrl, gw.offs_full,  \
-                       masks, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin, n)
+                       masks, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], gid_emit, gw.row_begin, n)
         if (flat)
             hipLaunchKernelGGL(k_bin_chunk<true>, dim3(bin_blocks), dim3(kBinBlock), 0, s, f, c, r0, r1, gw.order, gw.records,
-                               iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], bw.inst_gid, gw.row_begin);
+                               iw.open_bits, gw.ctrl, gw.cnt_open, gw.offs_open, bw.keys[0], bw.vals[0], gid_emit, gw.row_begin);
         else if (team == 16) GSR_ET(16);
         else if (team == 4) GSR_ET(4);
         else GSR_ET(1);
@@ -933,15 +941,20 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
         GSR_LAUNCH_CHECK("emit", debug, s);
     }
     if ((rc = launch_radix_sort<uint32_t>(bw.keys, bw.vals, &gw.ctrl->chunk_R[c], 0, n_max, &gw.ctrl->chunk_base[c], 0,
-                                          tile_bits > 0 ? tile_bits : 1, gw.radix_temp, sort_result, "tile_sort", debug, s)))
+                                          tile_bits > 0 ? tile_bits : 1, gw.radix_temp, sort_result, "tile_sort", debug, s, false,
+                                          carry_gid ? gid_pingpong : nullptr)))
         return rc;
     {
         ProfileScope prof("ranges", s);
         uint64_t blocks = (n_max + kBinBlock - 1) / kBinBlock;
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k_ranges, dim3((unsigned)blocks), dim3(kBinBlock), 0, s, c, gw.ctrl, bw.keys[*sort_result],
-                           bw.vals[*sort_result], bw.inst_gid, iw.ranges + (size_t)c * Tn, bw.sorted_gid);
+        if (carry_gid)
+            hipLaunchKernelGGL(k_ranges<false>, dim3((unsigned)blocks), dim3(kBinBlock), 0, s, c, gw.ctrl, bw.keys[*sort_result],
+                               nullptr, nullptr, iw.ranges + (size_t)c * Tn, nullptr);
+        else
+            hipLaunchKernelGGL(k_ranges<true>, dim3((unsigned)blocks), dim3(kBinBlock), 0, s, c, gw.ctrl, bw.keys[*sort_result],
+                               bw.vals[*sort_result], bw.gids[0], iw.ranges + (size_t)c * Tn, bw.gids[1]);
         GSR_LAUNCH_CHECK("ranges", debug, s);
     }
     return GSR_OK;

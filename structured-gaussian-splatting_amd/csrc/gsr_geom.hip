@@ -377,8 +377,23 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
     // overwrites it with its gradient, so one row serves both directions.
     const int wave_first = i - lane;                           // first Gaussian of this wave
     const int n_rows = min(64, g1 - wave_first);
-    const bool wave_live = __ballot(live) != 0ull;
-    if (sh_wanted_or_read(shs, has_colpre) && wave_live && rowf > 0 && n_rows > 0) {
+    const unsigned long long live_mask = __ballot(live);
+    const bool wave_live = live_mask != 0ull;
+    // few live lanes (a frame whose back Gaussians sit behind saturated pixels: 19 % live at 5e6 Gaussians / 4K, in index order
+    // every wave holds some): each live lane fetches its own row, three whole 64-byte sectors, instead of the wave staging all 64
+    // rows for a dozen readers (0.96 GB of the kernel's 2.6 GB there)
+    const bool own_rows = RAW != 1 && __popcll(live_mask) * 3 < 64 && rowf % 4 == 0 && (((uintptr_t)shs) & 15) == 0;
+    if (sh_wanted_or_read(shs, has_colpre) && wave_live && rowf > 0 && n_rows > 0 && own_rows) {
+        if (live) {
+            const float4 *src4 = reinterpret_cast<const float4 *>(shs + (size_t)i * rowf);
+            for (int e4 = 0; e4 < rowf / 4; ++e4) {
+                const float4 v = src4[e4];
+                my_row[4 * e4] = v.x; my_row[4 * e4 + 1] = v.y; my_row[4 * e4 + 2] = v.z; my_row[4 * e4 + 3] = v.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else if (sh_wanted_or_read(shs, has_colpre) && wave_live && rowf > 0 && n_rows > 0) {
         float *stage_w = sh_stage + wv * (64 * 49);
         if constexpr (RAW == 1) {
             for (int e = lane; e < n_rows * 3; e += 64) stage_w[(e / 3) * (rowf + 1) + e % 3] = shs[(size_t)wave_first * 3 + e];

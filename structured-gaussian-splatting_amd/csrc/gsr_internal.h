@@ -176,8 +176,10 @@ struct ImageWS {                // O(N + Tn): the reference's imgBuffer
 struct BinningWS {              // O(R): the reference's binningBuffer
     uint32_t *keys[2];          // [R] x2 tile id (radix double buffer)
     uint32_t *vals[2];          // [R] x2 payload = instance slot (absolute index in emission order)
-    uint32_t *inst_gid;         // [R] slot -> Gaussian | quadrant mask << 28 (gsr_math.h quadrant_mask_q of the instance's tile)
-    uint32_t *sorted_gid;       // [R] sorted position -> the same word
+    uint32_t *gids[2];          // [R] x2 Gaussian | quadrant mask << 28 (gsr_math.h quadrant_mask_q of the instance's tile): [1] by sorted
+                                //      position — what the blend kernels gather records by; the other side holds the word by slot as emitted
+                                //      (sorts of >= 4 M instances carry it through the radix passes as a second payload; smaller ones
+                                //      gather [1][p] = [0][slot at p] behind the sort)
     uint8_t *row_valid;         // [R] by slot: 1 = the blend backward wrote the instance's gradient row (cleared ahead of it: by the
                                 //      forward's zero fill, or by gsr_backward_render itself)
     float *ckpt;                // [R / kSeg + 2][kCkptFloats] the pixels' state in front of sorted position p = range start + k kSeg
@@ -189,7 +191,7 @@ struct BinningWS {              // O(R): the reference's binningBuffer
     size_t total;
 };
 constexpr int kLastShift = 26;  // last_enc = (chunk + 1) << kLastShift | position
-constexpr int kQuadMaskShift = 28;                // BinningWS::inst_gid / sorted_gid = quadrant mask << 28 | Gaussian (P < 2^28)
+constexpr int kQuadMaskShift = 28;                // BinningWS::gids = quadrant mask << 28 | Gaussian (P < 2^28)
 constexpr uint32_t kGidMask = (1u << kQuadMaskShift) - 1u;
 constexpr float kMassUnitsPerPixelNeper = 64.f;   // GeomWS::mass fixed point
 constexpr int kScanTileElems = 2048;              // elements per block of the prefix sums (= granularity of mass_blocks)
@@ -205,10 +207,11 @@ int launch_scan_inclusive(const uint32_t *in, uint32_t *out, int n, void *temp, 
                           uint32_t *acc_out, const char *name, bool debug, hipStream_t s, uint32_t *overflow = nullptr,
                           const uint32_t *gather = nullptr, const uint2 *aux = nullptr,
                           unsigned long long *aux_block_prefix = nullptr);
+// vals2: an optional second payload, carried along with vals
 template <typename K>
 int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
                       const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,
-                      bool debug, hipStream_t s, bool even_passes = false);
+                      bool debug, hipStream_t s, bool even_passes = false, uint32_t *const *vals2 = nullptr);
 
 // ---- kernel launchers (each returns a gsr_status)
 int launch_preprocess(const FrameK &f, const gsr_camera &cam, const gsr_gaussians &g, GeomWS &ws, int32_t *radii,
@@ -235,7 +238,7 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
                          ImageWS &iw,
                          int *sort_result, bool debug, hipStream_t s, bool filtered = false);
 int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s, CtrlMirror mirror = CtrlMirror());
-int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
+int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, int sort_result, const GeomWS &gw, const BinningWS &bw,
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s);
 // rows_upper: bound of the instances the chunks that ran emitted (sizes the launch: the unit count lives on the device)
 int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long long rows_upper, const GeomWS &gw, BinningWS &bw,

@@ -130,14 +130,15 @@ __device__ __forceinline__ unsigned stage_batch(float4 *sh_rec, int lane, int n,
 // arithmetic the two rules differ only where alpha sits within rounding of the threshold (the oracle's fragile band).
 constexpr float kLog2AlphaMin = -7.99435343685886f;      // log2(1 / 255)
 
-// Per pixel: Tl = live transmittance (0 once the pixel has taken the cut-off), Tf = transmittance to report (frozen at
-// the cut-off), colour, last contributor.  A rejected splat runs the same arithmetic with alpha = 0, which leaves
+// Per pixel: T (signed, see FwdPair), colour, last contributor.  A rejected splat runs the same arithmetic with alpha = 0, which leaves
 // everything unchanged, so the only selects are on alpha, on the stop decision and on the contributor index.
 struct FwdPair {             // state of a lane's two pixels in one pair of quadrants (left, right)
-    v2f Tl, Tf, Cr, Cg, Cb;
-    int last0, last1;
+    v2f T, Cr, Cg, Cb;       // T > 0: live transmittance; T < 0: the pixel has taken the cut-off (or lies outside the image), |T| = the
+    int last0, last1;        // transmittance to report (frozen in front of the stopping splat): exactly what T_state holds
 };
 
+// One register per pixel carries both "live transmittance" and "final transmittance of a done pixel": for a done pixel
+// test_T = T (1 - alpha) is negative, so the stop test fires by itself, nothing is composited and T keeps its value.
 template <int MODE>          // 3: both quadrants of the pair (packed), 1: the left one only, 2: the right one only
 __device__ __forceinline__ void fwd_pair(v2f lp, float lop, float cr, float cg, float cb, int contributor, FwdPair &P)
 {
@@ -147,26 +148,24 @@ __device__ __forceinline__ void fwd_pair(v2f lp, float lop, float cr, float cg, 
         // a rejected pixel gets lp = -inf: exp2 gives alpha = 0 by itself (one select per pixel, in front of the exponential)
         const v2f ae = {fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep0 ? lp[0] : -INFINITY)),
                         fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep1 ? lp[1] : -INFINITY))};
-        const v2f test_T = P.Tl * (1.f - ae);                      // == Tl when rejected, 0 when already done
-        const v2f aT = ae * P.Tl;
+        const v2f test_T = P.T * (1.f - ae);                       // == T when rejected, negative when already done
+        const v2f aT = ae * P.T;
         const bool stop0 = test_T[0] < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
         const bool stop1 = test_T[1] < (float)GSR_T_CUTOFF;
         const v2f w = {stop0 ? 0.f : aT[0], stop1 ? 0.f : aT[1]};  // the stopping splat is NOT composited (A.8)
         P.Cr += cr * w; P.Cg += cg * w; P.Cb += cb * w;
-        P.Tf = v2f{stop0 ? P.Tf[0] : test_T[0], stop1 ? P.Tf[1] : test_T[1]};
-        P.Tl = v2f{stop0 ? 0.f : test_T[0], stop1 ? 0.f : test_T[1]};
+        P.T = v2f{stop0 ? -fabsf(P.T[0]) : test_T[0], stop1 ? -fabsf(P.T[1]) : test_T[1]};
         P.last0 = (keep0 && !stop0) ? contributor : P.last0;
         P.last1 = (keep1 && !stop1) ? contributor : P.last1;
     } else {
         constexpr int e = MODE - 1;
         const bool keep = !(lp[e] > lop) && !(lp[e] < kLog2AlphaMin);
         const float ae = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep ? lp[e] : -INFINITY));
-        const float test_T = P.Tl[e] * (1.f - ae);
+        const float test_T = P.T[e] * (1.f - ae);
         const bool stop = test_T < (float)GSR_T_CUTOFF;
-        const float w = stop ? 0.f : ae * P.Tl[e];
+        const float w = stop ? 0.f : ae * P.T[e];
         P.Cr[e] += cr * w; P.Cg[e] += cg * w; P.Cb[e] += cb * w;
-        P.Tf[e] = stop ? P.Tf[e] : test_T;
-        P.Tl[e] = stop ? 0.f : test_T;
+        P.T[e] = stop ? -fabsf(P.T[e]) : test_T;
         if constexpr (e == 0) P.last0 = (keep && !stop) ? contributor : P.last0;
         else P.last1 = (keep && !stop) ? contributor : P.last1;
     }
@@ -185,10 +184,10 @@ __device__ __forceinline__ void fwd_pair_dispatch(unsigned mp, v2f lp, float lop
 __device__ __forceinline__ unsigned live_quadrants(const FwdPair &A, const FwdPair &B)
 {
     unsigned m = 0;
-    if (__ballot(A.Tl[0] != 0.f) != 0ull) m |= 1u;
-    if (__ballot(A.Tl[1] != 0.f) != 0ull) m |= 2u;
-    if (__ballot(B.Tl[0] != 0.f) != 0ull) m |= 4u;
-    if (__ballot(B.Tl[1] != 0.f) != 0ull) m |= 8u;
+    if (__ballot(A.T[0] > 0.f) != 0ull) m |= 1u;
+    if (__ballot(A.T[1] > 0.f) != 0ull) m |= 2u;
+    if (__ballot(B.T[0] > 0.f) != 0ull) m |= 4u;
+    if (__ballot(B.T[1] > 0.f) != 0ull) m |= 8u;
     return m;
 }
 
@@ -238,25 +237,23 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     const size_t N = (size_t)f.W * f.H;
 
     FwdPair P0, P1;
-    auto load_px = [&](int k, float &tf, float &tl, float &r_, float &g_, float &b_, int &last) {
+    auto load_px = [&](int k, float &t_, float &r_, float &g_, float &b_, int &last) {
         const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
         const bool inside = px < f.W && py < f.H;
-        tf = 1.f; tl = inside ? 1.f : 0.f; r_ = g_ = b_ = 0.f; last = 0;
+        t_ = inside ? 1.f : -1.f; r_ = g_ = b_ = 0.f; last = 0;
         if (c > 0 && inside) {
             const size_t pix = (size_t)py * f.W + px;
-            const float ts = T_state[pix];
-            tf = fabsf(ts);
-            tl = ts < 0.f ? 0.f : ts;
+            t_ = T_state[pix];
             r_ = out_color[pix]; g_ = out_color[N + pix]; b_ = out_color[2 * N + pix];
             last = last_enc[pix];
         }
     };
     {
-        float tf0, tl0, r0, g0, b0, tf1, tl1, r1, g1, b1;
-        load_px(0, tf0, tl0, r0, g0, b0, P0.last0); load_px(1, tf1, tl1, r1, g1, b1, P0.last1);
-        P0.Tf = v2f{tf0, tf1}; P0.Tl = v2f{tl0, tl1}; P0.Cr = v2f{r0, r1}; P0.Cg = v2f{g0, g1}; P0.Cb = v2f{b0, b1};
-        load_px(2, tf0, tl0, r0, g0, b0, P1.last0); load_px(3, tf1, tl1, r1, g1, b1, P1.last1);
-        P1.Tf = v2f{tf0, tf1}; P1.Tl = v2f{tl0, tl1}; P1.Cr = v2f{r0, r1}; P1.Cg = v2f{g0, g1}; P1.Cb = v2f{b0, b1};
+        float t0, r0, g0, b0, t1, r1, g1, b1;
+        load_px(0, t0, r0, g0, b0, P0.last0); load_px(1, t1, r1, g1, b1, P0.last1);
+        P0.T = v2f{t0, t1}; P0.Cr = v2f{r0, r1}; P0.Cg = v2f{g0, g1}; P0.Cb = v2f{b0, b1};
+        load_px(2, t0, r0, g0, b0, P1.last0); load_px(3, t1, r1, g1, b1, P1.last1);
+        P1.T = v2f{t0, t1}; P1.Cr = v2f{r0, r1}; P1.Cg = v2f{g0, g1}; P1.Cb = v2f{b0, b1};
     }
 
     const int n_total = (int)(rng.y - rng.x);
@@ -264,10 +261,10 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     // The blend backward walks this list front to back in independent segments of kSeg entries (gsr_bwd_units.h): it starts a
     // segment from the pixels' state (live transmittance, colour so far) in front of the segment's first entry, kept here.
     auto checkpoint = [&](float *dst) {                 // [quadrant][T, r, g, b][lane]: sixteen coalesced 256-byte stores
-        dst[0 * kWave + lane] = P0.Tl[0]; dst[1 * kWave + lane] = P0.Cr[0]; dst[2 * kWave + lane] = P0.Cg[0]; dst[3 * kWave + lane] = P0.Cb[0];
-        dst[4 * kWave + lane] = P0.Tl[1]; dst[5 * kWave + lane] = P0.Cr[1]; dst[6 * kWave + lane] = P0.Cg[1]; dst[7 * kWave + lane] = P0.Cb[1];
-        dst[8 * kWave + lane] = P1.Tl[0]; dst[9 * kWave + lane] = P1.Cr[0]; dst[10 * kWave + lane] = P1.Cg[0]; dst[11 * kWave + lane] = P1.Cb[0];
-        dst[12 * kWave + lane] = P1.Tl[1]; dst[13 * kWave + lane] = P1.Cr[1]; dst[14 * kWave + lane] = P1.Cg[1]; dst[15 * kWave + lane] = P1.Cb[1];
+        dst[0 * kWave + lane] = P0.T[0]; dst[1 * kWave + lane] = P0.Cr[0]; dst[2 * kWave + lane] = P0.Cg[0]; dst[3 * kWave + lane] = P0.Cb[0];
+        dst[4 * kWave + lane] = P0.T[1]; dst[5 * kWave + lane] = P0.Cr[1]; dst[6 * kWave + lane] = P0.Cg[1]; dst[7 * kWave + lane] = P0.Cb[1];
+        dst[8 * kWave + lane] = P1.T[0]; dst[9 * kWave + lane] = P1.Cr[0]; dst[10 * kWave + lane] = P1.Cg[0]; dst[11 * kWave + lane] = P1.Cb[0];
+        dst[12 * kWave + lane] = P1.T[1]; dst[13 * kWave + lane] = P1.Cr[1]; dst[14 * kWave + lane] = P1.Cg[1]; dst[15 * kWave + lane] = P1.Cb[1];
     };
     if (c > 0 && n_total > 0) checkpoint(ckpt_start_c + (size_t)tile * kCkptFloats);
     for (int base = 0; base < n_total; base += kWave) {
@@ -309,25 +306,26 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     const bool closing = live_quadrants(P0, P1) == 0u;
     const bool finalize = closing || finalize_all != 0;
     const float bg0 = finalize ? bg[0] : 0.f, bg1 = finalize ? bg[1] : 0.f, bg2 = finalize ? bg[2] : 0.f;
-    auto store_px = [&](int k, float tf, float tl, float r_, float g_, float b_, int last) {
+    auto store_px = [&](int k, float t_, float r_, float g_, float b_, int last) {
         const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
         if (px < f.W && py < f.H) {
             const size_t pix = (size_t)py * f.W + px;
+            const float tf = fabsf(t_);
             out_color[pix] = r_ + tf * bg0;
             out_color[N + pix] = g_ + tf * bg1;
             out_color[2 * N + pix] = b_ + tf * bg2;
-            T_state[pix] = tl == 0.f ? -tf : tf;
+            T_state[pix] = t_;
             last_enc[pix] = last;
         }
     };
-    store_px(0, P0.Tf[0], P0.Tl[0], P0.Cr[0], P0.Cg[0], P0.Cb[0], P0.last0);
-    store_px(1, P0.Tf[1], P0.Tl[1], P0.Cr[1], P0.Cg[1], P0.Cb[1], P0.last1);
-    store_px(2, P1.Tf[0], P1.Tl[0], P1.Cr[0], P1.Cg[0], P1.Cb[0], P1.last0);
-    store_px(3, P1.Tf[1], P1.Tl[1], P1.Cr[1], P1.Cg[1], P1.Cb[1], P1.last1);
+    store_px(0, P0.T[0], P0.Cr[0], P0.Cg[0], P0.Cb[0], P0.last0);
+    store_px(1, P0.T[1], P0.Cr[1], P0.Cg[1], P0.Cb[1], P0.last1);
+    store_px(2, P1.T[0], P1.Cr[0], P1.Cg[0], P1.Cb[0], P1.last0);
+    store_px(3, P1.T[1], P1.Cr[1], P1.Cg[1], P1.Cb[1], P1.last1);
     // 2 = open AND some pixel is still more than half transparent after everything so far: a tile no splat has covered yet
     // (the chunk plan merges the remaining chunks when such tiles exist: the frame is not going to close, gsr_api.hip)
-    auto clear_px = [&](int k, float tl) { return px0 + (k & 1) * 8 < f.W && py0 + (k >> 1) * 8 < f.H && tl > 0.5f; };
-    const bool stuck = __ballot(clear_px(0, P0.Tl[0]) || clear_px(1, P0.Tl[1]) || clear_px(2, P1.Tl[0]) || clear_px(3, P1.Tl[1])) != 0ull;
+    auto clear_px = [&](int k, float t_) { return px0 + (k & 1) * 8 < f.W && py0 + (k >> 1) * 8 < f.H && t_ > 0.5f; };
+    const bool stuck = __ballot(clear_px(0, P0.T[0]) || clear_px(1, P0.T[1]) || clear_px(2, P1.T[0]) || clear_px(3, P1.T[1])) != 0ull;
     // what the backward's wave will walk of this chunk's range: up to the tile's deepest contributor (launch order of K7)
     auto depth_here = [&](int last) { return (last >> kLastShift) == c + 1 ? (last & ((1 << kLastShift) - 1)) : 0; };
     const int walked = wave_max_uniform(max(max(depth_here(P0.last0), depth_here(P0.last1)), max(depth_here(P1.last0), depth_here(P1.last1))));
@@ -355,7 +353,7 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     }
 }
 
-int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, const GeomWS &gw, const BinningWS &bw,
+int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, int sort_result, const GeomWS &gw, const BinningWS &bw,
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s)
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
@@ -363,7 +361,7 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
     ProfileScope prof("render_fwd", s);
     const size_t Tn = (size_t)f.Gx * f.Gy;
     hipLaunchKernelGGL(k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, c, last_chunk ? 1 : 0,
-                       iw.ranges + (size_t)c * Tn, iw.open, bw.sorted_gid, gw.records, cam.bg, out_color, iw.T_state,
+                       iw.ranges + (size_t)c * Tn, iw.open, bw.gids[1], gw.records, cam.bg, out_color, iw.T_state,
                        iw.last_enc, iw.tile_walk + (size_t)c * Tn, bw.ckpt,
                        c > 0 ? iw.ckpt_start + (size_t)(c - 1) * Tn * kCkptFloats : nullptr, bw.units, iw.unit_count);
     GSR_LAUNCH_CHECK("render_fwd", debug, s);
@@ -664,7 +662,7 @@ int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long lon
     if (per_shard > (long long)bw.units.shard_stride()) per_shard = (long long)bw.units.shard_stride();
     if (per_shard > (1 << 13)) per_shard = 1 << 13;
     ProfileScope prof("render_bwd", s);
-    hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)(per_shard * kUnitShards)), dim3(kWave), 0, s, f, iw.ranges, iw.tile_walk, bw.sorted_gid,
+    hipLaunchKernelGGL(k_render_bwd, dim3((unsigned)(per_shard * kUnitShards)), dim3(kWave), 0, s, f, iw.ranges, iw.tile_walk, bw.gids[1],
                        bw.vals[sort_result], gw.records, out_color, iw.T_state, iw.last_enc, dL_dcolor, bw.ckpt, iw.ckpt_start,
                        reinterpret_cast<float4 *>(bw.grad_rows), bw.row_valid, bw.units, iw.unit_count);
     GSR_LAUNCH_CHECK("render_bwd", debug, s);

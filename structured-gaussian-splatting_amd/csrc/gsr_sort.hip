@@ -316,11 +316,13 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
                                                                const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                                const uint32_t *__restrict__ base_ptr, int shift, uint32_t dmask,
                                                                const uint32_t *__restrict__ table,
-                                                               const uint32_t *__restrict__ totals)
+                                                               const uint32_t *__restrict__ totals,
+                                                               const uint32_t *__restrict__ vals2_in, uint32_t *__restrict__ vals2_out)
 {
     if (base_ptr) {
         const uint32_t bo = *base_ptr;
         keys_in += bo; vals_in += bo; keys_out += bo; vals_out += bo;
+        if (vals2_in) { vals2_in += bo; vals2_out += bo; }
     }
     __shared__ uint32_t base[kRadixBins];                          // next global position per digit for this block
     __shared__ volatile uint32_t wave_cnt[kRadixBlock / kWave][kRadixBins];
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
                 const uint32_t dst = offs[w][d] + local[r];
                 keys_out[dst] = key[r];
                 vals_out[dst] = vals_in[idx];
+                if (vals2_in) vals2_out[dst] = vals2_in[idx];
             }
         }
         // the next sub-tile's first barrier orders these reads of offs[] before its rewrite
@@ -393,18 +396,21 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter(const K *__restri
 // every store instruction touches 64 different cache lines.
 constexpr int kBigRounds = 16;
 constexpr int kBigSubTile = kRadixBlock * kBigRounds;            // 4096 keys
-template <typename K>
+template <typename K, bool V2>          // V2: a second payload array travels with vals (its staging LDS only then)
 __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                                    K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
                                                                    const uint32_t *__restrict__ n_ptr, uint32_t n_host,
                                                                    const uint32_t *__restrict__ base_ptr, int shift, uint32_t dmask,
                                                                    const uint32_t *__restrict__ table,
-                                                                   const uint32_t *__restrict__ totals)
+                                                                   const uint32_t *__restrict__ totals,
+                                                                   const uint32_t *__restrict__ vals2_in, uint32_t *__restrict__ vals2_out)
 {
     if (base_ptr) {
         const uint32_t bo = *base_ptr;
         keys_in += bo; vals_in += bo; keys_out += bo; vals_out += bo;
+        if (vals2_in) { vals2_in += bo; vals2_out += bo; }
     }
+    __shared__ uint32_t sv2[V2 ? kBigSubTile : 1];
     __shared__ uint32_t base[kRadixBins];                          // next global position per digit for this block
     __shared__ uint32_t delta[kRadixBins];                         // global position minus position in the sorted sub-tile
     __shared__ volatile uint32_t wave_cnt[kRadixBlock / kWave][kRadixBins];
@@ -466,6 +472,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__re
                 const uint32_t p = offs[w][d] + local[r];
                 sk[p] = key[r];
                 sv[p] = vals_in[idx];
+                if constexpr (V2) sv2[p] = vals2_in[idx];
             }
         }
         __syncthreads();
@@ -475,6 +482,7 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__re
             const uint32_t dst = delta[(uint32_t)(kk >> shift) & dmask] + p;
             keys_out[dst] = kk;
             vals_out[dst] = sv[p];
+            if constexpr (V2) vals2_out[dst] = sv2[p];
         }
         __syncthreads();
     }
@@ -496,7 +504,7 @@ size_t radix_temp_bytes() { return align_up((size_t)kRadixBins * kRadixMaxBlocks
 template <typename K>
 int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t *n_ptr, uint32_t n_host, uint64_t n_max,
                       const uint32_t *base_ptr, int begin_bit, int end_bit, void *temp, int *result, const char *name,
-                      bool debug, hipStream_t s, bool even_passes)
+                      bool debug, hipStream_t s, bool even_passes, uint32_t *const *vals2)
 {
     *result = 0;
     if (n_max == 0 || end_bit <= begin_bit) return GSR_OK;
@@ -520,12 +528,16 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
         hipLaunchKernelGGL(k_radix_hist<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], n_ptr, n_host, base_ptr, shift, dmask, subtile,
                            table);
         hipLaunchKernelGGL(k_radix_scan, dim3(kRadixBins), dim3(kRadixBlock), 0, s, table, B, totals);
-        if (big)
-            hipLaunchKernelGGL(k_radix_scatter_big<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
-                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, dmask, table, totals);
+        if (big && vals2)
+            hipLaunchKernelGGL((k_radix_scatter_big<K, true>), dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, dmask, table, totals, vals2[cur], vals2[cur ^ 1]);
+        else if (big)
+            hipLaunchKernelGGL((k_radix_scatter_big<K, false>), dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, dmask, table, totals, nullptr, nullptr);
         else
             hipLaunchKernelGGL(k_radix_scatter<K>, dim3(B), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
-                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, dmask, table, totals);
+                               vals[cur ^ 1], n_ptr, n_host, base_ptr, shift, dmask, table, totals, vals2 ? vals2[cur] : nullptr,
+                               vals2 ? vals2[cur ^ 1] : nullptr);
         cur ^= 1;
         shift += bits;
     }
@@ -535,8 +547,8 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
 }
 
 template int launch_radix_sort<uint32_t>(uint32_t *const[2], uint32_t *const[2], const uint32_t *, uint32_t, uint64_t,
-                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t, bool);
+                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t, bool, uint32_t *const *);
 template int launch_radix_sort<uint64_t>(uint64_t *const[2], uint32_t *const[2], const uint32_t *, uint32_t, uint64_t,
-                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t, bool);
+                                         const uint32_t *, int, int, void *, int *, const char *, bool, hipStream_t, bool, uint32_t *const *);
 
 }  // namespace gsr
