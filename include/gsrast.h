@@ -87,7 +87,7 @@ typedef struct gsr_frame_plan {
     int32_t tile_order_ready;                     /* set by gsr_forward when its zero fill also cleared the blend backward's row-valid
                                                      flags (gsr_backward_render then skips that memset); cleared by
                                                      gsr_forward_render                                                         */
-    int32_t reserved_;
+    uint32_t key_max;                             /* no visible Gaussian's depth key exceeds it: the last chunk's sort skips the bits above */
 } gsr_frame_plan;
 
 typedef struct gsr_camera {      /* tensor fields of GaussianRasterizationSettings (device) */

@@ -345,6 +345,7 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     for (int c = 0; c <= GSR_MAX_CHUNKS; ++c) plan->chunk_rank_begin[c] = (int32_t)h.bnd[c];
     for (int c = 0; c < GSR_MAX_CHUNKS; ++c) plan->chunk_instances_max[c] = (int64_t)h.chunk_full[c];
     for (int c = 0; c < GSR_MAX_CHUNKS; ++c) plan->chunk_key_end[c] = h.key_end[c];
+    plan->key_max = h.key_max;
     if (h.num_chunks == 0)
         for (int c = 0; c <= GSR_MAX_CHUNKS; ++c) plan->chunk_rank_begin[c] = 0;
     return GSR_OK;
@@ -442,7 +443,9 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         if (filtered) plan->chunks_filtered |= 1 << c;
         if (c >= plan->chunks_sorted) {
             if (filtered && (rc = launch_live_filter(f, c, r0, r1, parts, gw, iw, dbg, s))) return rc;
-            if ((rc = launch_chunk_order(f, r0, r1, c > 0 ? plan->chunk_key_end[c - 1] : 0u, plan->chunk_key_end[c], c == 0, gw, dbg, s,
+            // (the sort's key span: up to the chunk's end, and never beyond the frame's largest key — the last chunk's end is "everything")
+            const uint32_t key_hi = plan->key_max != 0u && plan->key_max < plan->chunk_key_end[c] ? plan->key_max : plan->chunk_key_end[c];
+            if ((rc = launch_chunk_order(f, r0, r1, c > 0 ? plan->chunk_key_end[c - 1] : 0u, key_hi, c == 0, gw, dbg, s,
                                          filtered ? &gw.ctrl->chunk_live[c] : nullptr)))
                 return rc;
             plan->chunks_sorted = c + 1;

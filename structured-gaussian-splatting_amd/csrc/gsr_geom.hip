@@ -237,7 +237,19 @@ __global__ __launch_bounds__(kGeomBlock) void k_chunk_colors_all(FrameK f, const
     } else {
         const float *src = shs + (size_t)wave_first * rowf;
         const int total = n_rows * rowf;
-        if ((((uintptr_t)src) & 15) == 0 && rowf % 4 == 0) {
+        if ((((uintptr_t)src) & 15) == 0 && rowf == 3 * K && K == 16 && n_rows == 64) {
+            // the common shape (degree 3 stored and active, a full wave): all twelve 1-KB loads in flight before the first LDS store
+            const float4 *src4 = reinterpret_cast<const float4 *>(src);
+            float4 v[12];
+#pragma unroll
+            for (int it = 0; it < 12; ++it) v[it] = src4[lane + 64 * it];
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const int e = 4 * (lane + 64 * it), r = e / 48, c = e - r * 48;
+                float *d = stage + r * kRow + c;
+                d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+            }
+        } else if ((((uintptr_t)src) & 15) == 0 && rowf % 4 == 0) {
             const float4 *src4 = reinterpret_cast<const float4 *>(src);
             for (int e4 = lane; e4 < total / 4; e4 += 64) {
                 const float4 v = src4[e4];
@@ -405,7 +417,19 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
         } else {
             const float *src = shs + (size_t)wave_first * rowf;
             const int total = n_rows * rowf;
-            if ((((uintptr_t)src) & 15) == 0) {
+            if ((((uintptr_t)src) & 15) == 0 && rowf == 48 && n_rows == 64) {
+                // the common shape (16 coefficients, a full wave): all twelve 1-KB loads in flight before the first LDS store
+                const float4 *src4 = reinterpret_cast<const float4 *>(src);
+                float4 v[12];
+#pragma unroll
+                for (int it = 0; it < 12; ++it) v[it] = src4[lane + 64 * it];
+#pragma unroll
+                for (int it = 0; it < 12; ++it) {
+                    const int e = 4 * (lane + 64 * it), r = e / 48, c = e - r * 48;
+                    float *d = stage_w + r * 49 + c;
+                    d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+                }
+            } else if ((((uintptr_t)src) & 15) == 0) {
                 const float4 *src4 = reinterpret_cast<const float4 *>(src);
                 for (int e4 = lane; e4 < total / 4; e4 += 64) {
                     const float4 v = src4[e4];
@@ -479,7 +503,16 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd(FrameK f, int g0, int g
         } else if (n_rows > 0) {
             float *dst = out.shs + (size_t)wave_first * rowf;
             const int total = n_rows * rowf;
-            if (!any_live) { for (int e = lane; e < total; e += 64) dst[e] = 0.f; }
+            if (rowf == 48 && n_rows == 64 && (((uintptr_t)dst) & 15) == 0) {      // twelve 1-KB stores instead of forty-eight 256-B ones
+                float4 *dst4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll
+                for (int it = 0; it < 12; ++it) {
+                    const int e = 4 * (lane + 64 * it), r = e / 48, c = e - r * 48;
+                    const float *q = stage + r * 49 + c;
+                    dst4[lane + 64 * it] = any_live ? make_float4(q[0], q[1], q[2], q[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            else if (!any_live) { for (int e = lane; e < total; e += 64) dst[e] = 0.f; }
             else { for (int e = lane; e < total; e += 64) dst[e] = stage[(e / rowf) * (rowf + 1) + e % rowf]; }
         }
     }

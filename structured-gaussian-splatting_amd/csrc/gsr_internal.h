@@ -86,7 +86,7 @@ struct SelState {               // device scratch of the selection (zeroed at th
     unsigned long long base_tiles[kSelRefine], base_mass[kSelRefine];
     uint32_t coarse_bin[GSR_MAX_CHUNKS], coarse_cnt[GSR_MAX_CHUNKS];
     unsigned long long coarse_tiles[GSR_MAX_CHUNKS];
-    uint32_t V, pad_;
+    uint32_t V, max_bin;         // max_bin: the highest occupied level-1 bin
     unsigned long long R;
     uint32_t done[2];           // tickets of the two histogram kernels: their last block runs the plan step
     uint32_t blk_cnt[GSR_MAX_CHUNKS][kSelBlocks];
@@ -106,6 +106,7 @@ struct Ctrl {                   // small device-side control block of one frame
     uint32_t open_stuck;                       // open tiles with a pixel that is still more than half transparent (nothing covers it yet)
     uint32_t overflow;                         // 1 = the sum of tiles touched does not fit 32 bits
     uint32_t prefilter_violation;              // 1 = prefiltered was set and a Gaussian failed the frustum test (A.1)
+    uint32_t key_max;                          // no visible Gaussian's depth key exceeds it (upper edge of the highest occupied histogram bin)
 };
 struct GeomWS {                 // O(P): the reference's geomBuffer
     float4 *records;            // [P,3]  Splat records, by Gaussian

@@ -100,7 +100,13 @@ __device__ void sel_plan1(unsigned long long first_mass, SelState *st, uint32_t 
     __syncthreads();
     const int c = threadIdx.x;
     if (!write) return;
-    if (c == 0) { st->V = V; st->R = R; }
+    // the highest occupied bin: the largest key of the frame lies in it (the last chunk's sort needs no bits above that)
+#pragma unroll
+    for (int k = 0; k < kSelPerThread; ++k) {
+        const int b = kSelPerThread * threadIdx.x + k;
+        if (V > 0u && cum_n[b] >= V && (b == 0 || cum_n[b - 1] < V)) st->max_bin = (uint32_t)b;
+    }
+    if (c == 0) { st->V = V; st->R = R; if (V == 0u) st->max_bin = 0u; }
     if (c < GSR_MAX_CHUNKS - 1) {
         const uint32_t b = sh_first[c];                         // kSelBins: no boundary, the chunk takes everything left
         st->coarse_bin[c] = b;
@@ -169,6 +175,10 @@ __device__ void sel_plan2(unsigned long long first_mass, const SelState *st, Ctr
     for (int k = 0; k < GSR_MAX_CHUNKS; ++k) { ctrl->key_end[k] = p_key[k]; ctrl->bnd[k + 1] = p_cnt[k]; ctrl->chunk_full[k] = p_full[k]; }
     for (int k = 0; k < GSR_MAX_CHUNKS; ++k) { ctrl->chunk_R[k] = 0; ctrl->chunk_base[k + 1] = 0; ctrl->chunk_live[k] = 0xFFFFFFFFu; }
     ctrl->bnd[0] = 0; ctrl->chunk_base[0] = 0;
+    {
+        const unsigned long long edge = ((unsigned long long)(st->max_bin + 1u) << kSelShift1) - 1ull;
+        ctrl->key_max = edge > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)edge;
+    }
     ctrl->V = V;
     ctrl->R_total = R > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)R;
     ctrl->overflow = R > 0xFFFFFFFFull ? 1u : 0u;

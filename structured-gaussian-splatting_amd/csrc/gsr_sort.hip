@@ -488,6 +488,22 @@ __global__ __launch_bounds__(kRadixBlock) void k_radix_scatter_big(const K *__re
     }
 }
 
+// keys / vals of buffer 1 back into buffer 0 (a caller that needs its result in place, after an odd number of passes): one
+// streaming launch instead of a fourth radix pass (three launches)
+template <typename K>
+__global__ __launch_bounds__(kRadixBlock) void k_radix_copy_back(const K *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                                 K *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+                                                                 const uint32_t *__restrict__ n_ptr, uint32_t n_host,
+                                                                 const uint32_t *__restrict__ base_ptr)
+{
+    const uint32_t n = n_ptr ? *n_ptr : n_host;
+    const uint32_t bo = base_ptr ? *base_ptr : 0u;
+    for (uint32_t i = blockIdx.x * kRadixBlock + threadIdx.x; i < n; i += gridDim.x * kRadixBlock) {
+        keys_out[bo + i] = keys_in[bo + i];
+        vals_out[bo + i] = vals_in[bo + i];
+    }
+}
+
 int radix_blocks(uint64_t n_max)
 {
     uint64_t b = (n_max + 2047) / 2048;          // ~2 sub-tiles per block: enough blocks to fill 256 CUs early (1024 and 4096
@@ -519,8 +535,8 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
     // digits: as few passes as 8-bit digits need, the key bits spread evenly over them (13 tile-id bits sort as
     // 7 + 6, not 8 + 5: fewer bins in the first pass means longer contiguous runs in its scatter)
     const int total_bits = end_bit - begin_bit;
-    int passes = (total_bits + 7) / 8;
-    if (even_passes && (passes & 1)) ++passes;          // the caller wants the result back in buffer 0 (a 0-bit pass copies)
+    const int passes = (total_bits + 7) / 8;
+    const bool copy_back = even_passes && (passes & 1);          // the caller wants the result back in buffer 0
     int shift = begin_bit;
     for (int p = 0; p < passes; ++p) {
         const int left = end_bit - shift, bits = (left + (passes - p) - 1) / (passes - p);
@@ -540,6 +556,13 @@ int launch_radix_sort(K *const keys[2], uint32_t *const vals[2], const uint32_t 
                                vals2 ? vals2[cur ^ 1] : nullptr);
         cur ^= 1;
         shift += bits;
+    }
+    if (copy_back) {
+        uint64_t blocks = (n_max + 4 * kRadixBlock - 1) / (4 * kRadixBlock);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_radix_copy_back<K>, dim3((unsigned)(blocks ? blocks : 1)), dim3(kRadixBlock), 0, s, keys[cur], vals[cur], keys[cur ^ 1],
+                           vals[cur ^ 1], n_ptr, n_host, base_ptr);
+        cur ^= 1;
     }
     *result = cur;
     GSR_LAUNCH_CHECK(name, debug, s);

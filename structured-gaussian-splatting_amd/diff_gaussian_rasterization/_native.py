@@ -53,7 +53,7 @@ class FramePlan(C.Structure):
                 ("chunks_run", C.c_int32), ("sort_result", C.c_int32), ("instances_emitted", C.c_int64),
                 ("binning_initialised", C.c_int32), ("screen_prezeroed", C.c_int32), ("binning_capacity", C.c_int64),
                 ("chunk_key_end", C.c_uint32 * MAX_CHUNKS), ("chunks_sorted", C.c_int32), ("chunks_filtered", C.c_int32),
-                ("tile_order_ready", C.c_int32), ("reserved_", C.c_int32)]
+                ("tile_order_ready", C.c_int32), ("key_max", C.c_uint32)]
 
 
 class DebugViews(C.Structure):
