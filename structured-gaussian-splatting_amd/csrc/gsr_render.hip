@@ -8,7 +8,7 @@
 //     and early termination is a wave ballot per quadrant.
 //   * splat records (48 B: xy, conic, opacity, rgb) are gathered 64 at a time, one per lane, staged in
 //     LDS and read back as wave-uniform broadcasts (ds_read_b128, conflict-free by construction).
-//   * backward: FRONT TO BACK, in independent work units of kSeg list entries (gsr_bwd_units.h) that start from the
+//   * backward: FRONT TO BACK, in independent work units of kSeg list entries (gsr_internal.h: kSeg, UnitLists) that start from the
 //     per-pixel state the forward left at the segment boundary.  Each lane first sums a splat's nine partial gradients
 //     over its own four pixels in registers, then a DPP reduction crosses the 64 lanes (two splats per tree); the
 //     wave's result goes to the splat's private 48-B row (no atomics).  Splats that no pixel of the tile
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
 
     const int n_total = (int)(rng.y - rng.x);
     const int enc_base = (c + 1) << kLastShift;
-    // The blend backward walks this list front to back in independent segments of kSeg entries (gsr_bwd_units.h): it starts a
+    // The blend backward walks this list front to back in independent segments of kSeg entries (gsr_internal.h): it starts a
     // segment from the pixels' state (live transmittance, colour so far) in front of the segment's first entry, kept here.
     auto checkpoint = [&](float *dst) {                 // [quadrant][T, r, g, b][lane]: sixteen coalesced 256-byte stores
         dst[0 * kWave + lane] = P0.T[0]; dst[1 * kWave + lane] = P0.Cr[0]; dst[2 * kWave + lane] = P0.Cg[0]; dst[3 * kWave + lane] = P0.Cb[0];

@@ -61,5 +61,5 @@ np.save(os.path.join(ROOT, "gpurun_out", "tile_work_%s.npy" % W), work.reshape(G
 # how well does the list LENGTH (known before the blend) predict the walked depth (known after)?
 l0 = lens.sum(axis=0).astype(float)
 print("list length per tile: mean %.1f max %d; corr(length, walked) = %.3f" % (l0.mean(), l0.max(), np.corrcoef(l0, work)[0, 1]))
-fw = v["tile_work"].cpu().numpy().astype(float)
+fw = v["tile_walk"][:fr.plan.chunks_run].sum(0).cpu().numpy().astype(float)
 print("forward-recorded tile_work vs this estimate: max abs diff", np.abs(fw - work).max())
