@@ -86,8 +86,10 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
         "scan_tiles": 12 * Vb, "open_count": 8 * Tn,        # chunks beyond the one-block sort: the scan gathers tiles[order[r]] itself
         "count_open": 56 * Vb, "scan_open": 8 * Vb,         # rank -> Gaussian 4 + record 48 + count 4
         "emit": 12 * Re + 56 * Vb,                          # K3: key 4 + slot 4 + Gaussian 4 per instance
-        "tile_sort": 16 * Re,                               # K4 minimum: one read + one write of (tile, slot)
-        "ranges": 16 * Re + 8 * Tn,                         # K5 (+ sorted position -> Gaussian)
+        # K4 minimum: one read + one write of (tile, slot); sorts of >= 4 M instances carry the Gaussian word along (12 B each way)
+        # and K5 then only reads the sorted keys; smaller ones gather it in K5 (slot in, Gaussian in + out)
+        "tile_sort": (24 if Re >= (4 << 20) else 16) * Re,
+        "ranges": (4 if Re >= (4 << 20) else 16) * Re + 8 * Tn,
         # gather variant of K3-K5 (chunks of few large splats): counts in, ranges out; then per instance the accept bit's
         # mask word 8 + prefix 4 in, (Gaussian, slot) 8 out, per rank 32 B of metadata
         "tile_ranges": 12 * Tn, "tile_gather": 20 * Re + 32 * Vb,

@@ -220,14 +220,18 @@ def rasterize_forward(means3D, sh, colors_precomp, opacities, scales, rotations,
     return color, fr.radii, fr
 
 
-def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor) -> torch.Tensor:
-    """K7 + deterministic per-Gaussian reduction -> screen-space gradients [P, 12]."""
+def rasterize_backward_screen(fr: "_Frame", grad_color: torch.Tensor, only_for_own_geom: bool = False) -> torch.Tensor:
+    """K7 + deterministic per-Gaussian reduction -> screen-space gradients [P, 12].
+    only_for_own_geom: the tensor goes straight into this frame's geometry backward and nowhere else (the autograd path): rows it
+    never reads may stay undefined.  The dense geometry backward reads the rows of VISIBLE Gaussians; when every planned chunk ran,
+    all of them sit in the binned prefix, whose rows the reduction writes (zeros included): no 48 P-byte memset."""
     P = fr.desc.P
     grad_color = _f32c(grad_color, fr.device)
     screen = fr.pre.pop("screen", None) if fr.pre is not None else None        # allocated (and, on sparse frames, zero-filled) by the forward
     if screen is None:
         screen = torch.empty(max(P, 1), N.SCREEN_GRAD_STRIDE, dtype=torch.float32, device=fr.device)
-        fr.plan.screen_prezeroed = 0            # (set only by prepare_backward(), for the very tensor it filled)
+        covered = fr.plan.num_rendered > 0 and fr.plan.chunks_run == fr.plan.num_chunks
+        fr.plan.screen_prezeroed = 2 if (only_for_own_geom and covered) else 0            # (1: set only by prepare_backward(), for the very tensor it filled)
     if grad_color is None:
         return screen.zero_()[:P]
     with torch.cuda.device(fr.device):
@@ -392,7 +396,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         order = (needs[0], needs[1], needs[2], needs[3], needs[4], needs[5], needs[6], needs[7])
 
         def run():
-            screen = rasterize_backward_screen(fr, grad_out_color)
+            screen = rasterize_backward_screen(fr, grad_out_color, only_for_own_geom=True)
             return rasterize_backward_geom(fr, screen, order)
         if rs.debug:
             try:
@@ -442,7 +446,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         fr = _unstash_frame(ctx)
         n = ctx.needs_input_grad       # xyz, means2D, f_dc, f_rest, opacity, scales, rotations
         needs = (n[0], n[1], n[2], False, n[4], n[5], n[6], False, n[3])
-        screen = rasterize_backward_screen(fr, grad_out_color)
+        screen = rasterize_backward_screen(fr, grad_out_color, only_for_own_geom=True)
         g_xyz, g_means2D, g_dc, _, g_op, g_sc, g_rot, _, g_rest = rasterize_backward_geom(fr, screen, needs)
         if g_op is not None:
             g_op = g_op.view(ctx.shapes[1])
