@@ -2,17 +2,17 @@
 // per-Gaussian reduction of the backward's instance rows.  Spec: SURVEY A.8 / A.9.
 //
 // MI355X mapping ("one wave, one tile"):
-//   * a 16x16 binning tile is blended by ONE wave64; lane l owns the pixel (l & 7, l >> 3) of each of the tile's
+//   * forward: a 16x16 binning tile is blended by ONE wave64; lane l owns the pixel (l & 7, l >> 3) of each of the tile's
 //     four 8x8 QUADRANTS, so "can this splat reach quadrant k at all" is wave-uniform and clear quadrants are
 //     skipped with scalar branches (sub-tile culling); no workgroup barrier exists anywhere in the blend loop,
 //     and early termination is a wave ballot per quadrant.
 //   * splat records (48 B: xy, conic, opacity, rgb) are gathered 64 at a time, one per lane, staged in
-//     LDS and read back as wave-uniform broadcasts (ds_read_b128, conflict-free by construction).
+//     LDS and read back as broadcasts (ds_read_b128).
 //   * backward: FRONT TO BACK, in independent work units of kSeg list entries (gsr_internal.h: kSeg, UnitLists) that start from the
-//     per-pixel state the forward left at the segment boundary.  Each lane first sums a splat's nine partial gradients
-//     over its own four pixels in registers, then a DPP reduction crosses the 64 lanes (two splats per tree); the
-//     wave's result goes to the splat's private 48-B row (no atomics).  Splats that no pixel of the tile
-//     accepts skip the reduction (wave-uniform ballot) and their row is never written (one valid byte per row).
+//     per-pixel state the forward left at the segment boundary.  The wave is four GROUPS of 16 lanes, one per quadrant, each
+//     walking the entries that reach ITS quadrant: up to four different splats per pass, one DPP butterfly over the rows of 16
+//     lanes for all four (k_render_bwd).  The sums of a batch of 64 entries meet in LDS and leave as whole 48-B rows, one per
+//     list entry (no global atomics; one valid byte per row says whether it was written).
 //   * workgroup = one wave (64 threads); forward: tile = block (consecutive tiles run on different XCDs).
 #include "gsr_internal.h"
 
@@ -26,54 +26,30 @@ __device__ __forceinline__ float fast_exp(float x)
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// Wave reduction of the blend backward: NINE sums per splat over the 64 lanes, TWO splats per call (a[] the first splat's nine
-// lane sums, b[] the second's), as a butterfly that halves the data with the lanes instead of carrying all nine values through
-// every step:
-//   1. v_permlane32_swap trades a's upper 32 lanes for b's lower 32: a + b = "first splat, lanes l and l + 32" in the lower half
-//      of the wave and "second splat" in the upper half                                             (9 swaps, 9 adds -> 9 values on 32 lanes)
-//   2. v_permlane16_swap on the register pairs (k, k + 5) trades odd rows of one for even rows of the other: the sum holds value k
-//      in a half's even row and value k + 5 in its odd row (value 4's partner is a zero)            (5 swaps, 5 adds -> 5 values on 16 lanes)
-//   3. inside a row of 16 lanes, DPP adds with BANK masks: lane i + lane i ^ 8 (row_ror:8) with values (0, 3) and (1, 4) sharing a
-//      register by row half; lane i + lane 7 - i (row_half_mirror) with (0 | 1 | 3 | 4) sharing one register by bank; the last two
-//      steps inside each quad                                                                        (5 + 3 + 4 DPP adds)
-// 42 instructions per two splats instead of 63 for two nine-value trees.  Where the totals land (h = lane & 31; first splat in
-// lanes 0..31, second in 32..63; every lane of a quad holds the quad's value):
-//   a[0]: quad of h = 0: value 0, h = 4: 1, h = 8: 3, h = 12: 4, h = 16: 5, h = 20: 6, h = 24: 8;   a[2]: h < 16: value 2, h >= 16: 7;
-//   a[1]: quad of h = 0: value 1 (a copy, so that one lane holds values 0, 1 and 2).
+// Nine sums over each ROW of 16 lanes, all four rows at once (k_render_bwd's quadrant groups): a transposing butterfly.  The first
+// two steps fold two values per instruction (bank_mask picks the half / the quads that keep a value), the two steps inside a quad
+// run on the three registers that are left: 20 DPP adds for four splats.  On return every lane of a quad holds, with b = the quad's
+// number in the row:   a[0]: value (0, 1, 4, 5)[b]     a[2]: value (2, 3, 6, 7)[b]     a[8]: value 8
 // DPP hazard (a VALU write followed by a DPP read of the same register needs two wait states) is covered by the order and s_nops.
-__device__ __forceinline__ void wave_sum9_two(float (&a)[9], float (&b)[9])
+__device__ __forceinline__ void row_sum9_transpose(float (&a)[9])
 {
-#define GSR_SWAP32(i, j) "v_permlane32_swap_b32 %" #i ", %" #j "\n\t"
-#define GSR_SWAP16(i, j) "v_permlane16_swap_b32 %" #i ", %" #j "\n\t"
-#define GSR_ADD(i, j) "v_add_f32 %" #i ", %" #i ", %" #j "\n\t"
 #define GSR_DPP(d, s_, ctrl, bank) "v_add_f32_dpp %" #d ", %" #s_ ", %" #s_ " " ctrl " row_mask:0xf bank_mask:" bank "\n\t"
     asm volatile("s_nop 1\n\t"
-                 GSR_SWAP32(0, 9) GSR_SWAP32(1, 10) GSR_SWAP32(2, 11) GSR_SWAP32(3, 12) GSR_SWAP32(4, 13) GSR_SWAP32(5, 14)
-                 GSR_SWAP32(6, 15) GSR_SWAP32(7, 16) GSR_SWAP32(8, 17)
-                 GSR_ADD(0, 9) "v_mov_b32 %9, 0\n\t" GSR_ADD(1, 10) GSR_ADD(2, 11) GSR_ADD(3, 12) GSR_ADD(4, 13) GSR_ADD(5, 14)
-                 GSR_ADD(6, 15) GSR_ADD(7, 16) GSR_ADD(8, 17)
+                 GSR_DPP(0, 0, "row_ror:8", "0x3") GSR_DPP(1, 1, "row_ror:8", "0x3") GSR_DPP(2, 2, "row_ror:8", "0x3")
+                 GSR_DPP(3, 3, "row_ror:8", "0x3") GSR_DPP(8, 8, "row_ror:8", "0xf")
+                 GSR_DPP(0, 4, "row_ror:8", "0xc") GSR_DPP(1, 5, "row_ror:8", "0xc") GSR_DPP(2, 6, "row_ror:8", "0xc")
+                 GSR_DPP(3, 7, "row_ror:8", "0xc")
                  "s_nop 1\n\t"
-                 GSR_SWAP16(0, 5) GSR_SWAP16(1, 6) GSR_SWAP16(2, 7) GSR_SWAP16(3, 8) GSR_SWAP16(4, 9)
-                 GSR_ADD(0, 5) GSR_ADD(1, 6) GSR_ADD(2, 7) GSR_ADD(3, 8) GSR_ADD(4, 9)
-                 "s_nop 1\n\t"
-                 GSR_DPP(0, 0, "row_ror:8", "0x3") GSR_DPP(0, 3, "row_ror:8", "0xc")
-                 GSR_DPP(1, 1, "row_ror:8", "0x3") GSR_DPP(1, 4, "row_ror:8", "0xc")
-                 GSR_DPP(2, 2, "row_ror:8", "0xf")
-                 "s_nop 0\n\t"
-                 GSR_DPP(0, 0, "row_half_mirror", "0x5") "s_nop 0\n\t" GSR_DPP(0, 1, "row_half_mirror", "0xa")
-                 GSR_DPP(2, 2, "row_half_mirror", "0xf")
+                 GSR_DPP(0, 0, "row_half_mirror", "0x5") GSR_DPP(2, 2, "row_half_mirror", "0x5") GSR_DPP(8, 8, "row_half_mirror", "0xf")
+                 GSR_DPP(0, 1, "row_half_mirror", "0xa") GSR_DPP(2, 3, "row_half_mirror", "0xa")
                  "s_nop 1\n\t"
                  GSR_DPP(0, 0, "quad_perm:[1,0,3,2]", "0xf") GSR_DPP(2, 2, "quad_perm:[1,0,3,2]", "0xf")
-                 "s_nop 1\n\t"
+                 GSR_DPP(8, 8, "quad_perm:[1,0,3,2]", "0xf")
+                 "s_nop 0\n\t"
                  GSR_DPP(0, 0, "quad_perm:[2,3,0,1]", "0xf") GSR_DPP(2, 2, "quad_perm:[2,3,0,1]", "0xf")
-                 "s_nop 1\n\t"
-                 "v_mov_b32_dpp %1, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+                 GSR_DPP(8, 8, "quad_perm:[2,3,0,1]", "0xf")
                  "s_nop 1"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]),
-                   "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]));
-#undef GSR_SWAP32
-#undef GSR_SWAP16
-#undef GSR_ADD
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]));
 #undef GSR_DPP
 }
 
@@ -92,8 +68,8 @@ __device__ __forceinline__ int wave_max_uniform(int v)
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 operand: the lane's two pixels of a pair
 
-// Pixel mapping ("one wave, one tile", QUADRANT-major): lane l owns the pixel (l & 7, l >> 3) of each of the tile's four
-// 8x8 quadrants.  Whether a splat can reach a quadrant at all (quadrant_mask_q: the exact alpha >= 1/255 bound on the 8x8
+// Pixel mapping of the FORWARD ("one wave, one tile", QUADRANT-major; the backward has its own, see k_render_bwd): lane l owns the
+// pixel (l & 7, l >> 3) of each of the tile's four 8x8 quadrants.  Whether a splat can reach a quadrant at all (quadrant_mask_q: the exact alpha >= 1/255 bound on the 8x8
 // pixel rectangle) is then WAVE-UNIFORM: a batch's staging lane computes the 4-bit mask with its record, and the blend
 // loops skip clear quadrants with scalar branches.  A 2-3 px splat reaches one or two quadrants of a tile, not four.
 // The two quadrants of a pair share dy and differ by 8 in dx: when both are wanted they run as packed fp32 (v_pk_fma_f32
@@ -177,7 +153,7 @@ __device__ __forceinline__ void fwd_pair_dispatch(unsigned mp, v2f lp, float lop
     if (mp == 1u) { fwd_pair<1>(lp, lop, cr, cg, cb, contributor, P); return; }
     if (mp == 2u) { fwd_pair<2>(lp, lop, cr, cg, cb, contributor, P); return; }
 #endif
-    fwd_pair<3>(lp, lop, cr, cg, cb, contributor, P);      // a clear mask bit / a dead quadrant rejects on its own (see bwd_pair_dispatch)
+    fwd_pair<3>(lp, lop, cr, cg, cb, contributor, P);      // a clear mask bit / a dead quadrant rejects on its own (the backward does the same)
 }
 
 // wave-uniform 4-bit mask: quadrant k still has a live pixel
@@ -390,10 +366,10 @@ int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_c
 // per pixel (dL/dopacity = sum(G dL/dalpha) = sum(ga dL/dalpha) / opacity: one division per splat, after the reduction), and
 // the conic enters through the pre-scaled record fields directly: cA = -2 ln2 qA, cB = -ln2 qB, cC = -2 ln2 qC, so
 // -(tx cA + ty cB) = ln2 (2 qA tx + qB ty): the factor ln2 goes into the row store.
-struct BwdSplat {            // wave-uniform per-splat values
+struct BwdSplat {            // per-splat values (uniform over a 16-lane group)
     float lop, cr, cg, cb;
 };
-struct BwdPair {             // state of a lane's two pixels in one pair of quadrants (left, right)
+struct BwdPair {             // state of a lane's pair of pixels (4 apart in x, the same row)
     v2f T, E, dpr, dpg, dpb;           // transmittance in front of the current splat; E = Q - D: what everything behind the current
                                        // splat (and the background) still adds to <pixel, dL/dpix>; dL/dpix
     int limit0, limit1;                // contributors of the current chunk each pixel takes part in
@@ -408,70 +384,52 @@ __device__ __forceinline__ float add_halves(v2f v)
     return r;
 }
 
-template <int MODE>          // 3: both quadrants of the pair (packed), 1: the left one only, 2: the right one only
-__device__ __forceinline__ bool bwd_pair(const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
+template <bool INIT>         // INIT: the splat's first pair, the sums start here (A comes in undefined)
+__device__ __forceinline__ void bwd_pair(const BwdSplat sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
 {
-    if constexpr (MODE == 3) {
-        const bool valid0 = (pos < P.limit0) && !(lp[0] > sp.lop) && !(lp[0] < kLog2AlphaMin);      // power > 0 <=> lp > lop
-        const bool valid1 = (pos < P.limit1) && !(lp[1] > sp.lop) && !(lp[1] < kLog2AlphaMin);
-        // a rejected pixel gets lp = -inf: ga = opacity * G and alpha come out 0 by themselves
-        const v2f ga = {__builtin_amdgcn_exp2f(valid0 ? lp[0] : -INFINITY), __builtin_amdgcn_exp2f(valid1 ? lp[1] : -INFINITY)};
-        const v2f ae = {fminf((float)GSR_ALPHA_MAX, ga[0]), fminf((float)GSR_ALPHA_MAX, ga[1])};
-        const v2f one_m = 1.f - ae;
-        const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
-        const v2f cdp = sp.cr * P.dpr + sp.cg * P.dpg + sp.cb * P.dpb;      // <c_i, dL/dpix>
-        const v2f w = ae * P.T;                                              // d colour / d rgb
-        P.E -= w * cdp;                                                      // this splat's own share leaves the remainder
-        const v2f dL_dalpha = P.T * cdp - P.E * inv1ma;
-        P.T = P.T * one_m;                                                   // exactly the forward's update
-        const v2f tA = dL_dalpha * ga;
-        const v2f tx = tA * dx, ty = tA * dy;
+    const bool valid0 = (pos < P.limit0) && !(lp[0] > sp.lop) && !(lp[0] < kLog2AlphaMin);      // power > 0 <=> lp > lop
+    const bool valid1 = (pos < P.limit1) && !(lp[1] > sp.lop) && !(lp[1] < kLog2AlphaMin);
+    // a rejected pixel gets lp = -inf: ga = opacity * G and alpha come out 0 by themselves
+    const v2f ga = {__builtin_amdgcn_exp2f(valid0 ? lp[0] : -INFINITY), __builtin_amdgcn_exp2f(valid1 ? lp[1] : -INFINITY)};
+    const v2f ae = {fminf((float)GSR_ALPHA_MAX, ga[0]), fminf((float)GSR_ALPHA_MAX, ga[1])};
+    const v2f one_m = 1.f - ae;
+    const v2f inv1ma = {fast_rcp(one_m[0]), fast_rcp(one_m[1])};
+    const v2f cdp = sp.cr * P.dpr + sp.cg * P.dpg + sp.cb * P.dpb;      // <c_i, dL/dpix>
+    const v2f w = ae * P.T;                                              // d colour / d rgb
+    P.E -= w * cdp;                                                      // this splat's own share leaves the remainder
+    const v2f dL_dalpha = P.T * cdp - P.E * inv1ma;
+    P.T = P.T * one_m;                                                   // exactly the forward's update
+    const v2f tA = dL_dalpha * ga;
+    const v2f tx = tA * dx, ty = tA * dy;
+    if constexpr (INIT) {
+        A.X = tx; A.Y = ty;
+        A.S2 = tx * dx;
+        A.S3 = tx * dy;
+        A.S4 = ty * dy;
+        A.S5 = tA;
+        A.S6 = w * P.dpr; A.S7 = w * P.dpg; A.S8 = w * P.dpb;
+    } else {
         A.X += tx; A.Y += ty;
         A.S2 += tx * dx;
         A.S3 += tx * dy;
         A.S4 += ty * dy;
         A.S5 += tA;
         A.S6 += w * P.dpr; A.S7 += w * P.dpg; A.S8 += w * P.dpb;
-        return valid0 || valid1;
-    } else {
-        // one wanted quadrant: plain fp32 on that element only
-        constexpr int e = MODE - 1;
-        const bool valid = (pos < (e ? P.limit1 : P.limit0)) && !(lp[e] > sp.lop) && !(lp[e] < kLog2AlphaMin);
-        const float ga = __builtin_amdgcn_exp2f(valid ? lp[e] : -INFINITY);
-        const float ae = fminf((float)GSR_ALPHA_MAX, ga);
-        const float one_m = 1.f - ae;
-        const float inv1ma = fast_rcp(one_m);
-        const float cdp = sp.cr * P.dpr[e] + sp.cg * P.dpg[e] + sp.cb * P.dpb[e];
-        const float w = ae * P.T[e];
-        P.E[e] -= w * cdp;
-        const float dL_dalpha = P.T[e] * cdp - P.E[e] * inv1ma;
-        P.T[e] = P.T[e] * one_m;
-        const float tA = dL_dalpha * ga;
-        const float tx = tA * dx[e], ty = tA * dy;
-        A.X[e] += tx; A.Y[e] += ty;
-        A.S2[e] += tx * dx[e];
-        A.S3[e] += tx * dy;
-        A.S4[e] += ty * dy;
-        A.S5[e] += tA;
-        A.S6[e] += w * P.dpr[e]; A.S7[e] += w * P.dpg[e]; A.S8[e] += w * P.dpb[e];
-        return valid;
     }
 }
 
-// mp = the pair's two mask bits.  GSR_BWD_SINGLE = 0: a pair always runs packed (a clear mask bit means that no pixel of that
-// quadrant accepts the splat, so its lanes of the packed arithmetic find `valid` false on their own).
-#ifndef GSR_BWD_SINGLE
-#define GSR_BWD_SINGLE 0      // measured at cfg3n: 641 us with the single-quadrant variants, 616 without (code size, 7 spilled registers)
-#endif
-__device__ __forceinline__ bool bwd_pair_dispatch(unsigned mp, const BwdSplat &sp, v2f lp, v2f dx, float dy, int pos, BwdPair &P, BwdAcc &A)
-{
-#if GSR_BWD_SINGLE
-    if (mp == 1u) return bwd_pair<1>(sp, lp, dx, dy, pos, P, A);
-    if (mp == 2u) return bwd_pair<2>(sp, lp, dx, dy, pos, P, A);
-#endif
-    return bwd_pair<3>(sp, lp, dx, dy, pos, P, A);
-}
-
+#ifndef GSR_BWD_ORDERED_ADDS
+#define GSR_BWD_ORDERED_ADDS 1     // groups that meet on an entry in one pass add to its LDS sums one group after the other: the order of
+#endif                             // every floating-point sum is fixed by the program (0: one LDS instruction for all four, 2 % faster)
+// The kernel: one wave per work unit, front to back from the forward's checkpoint, with the wave split into four GROUPS of 16 lanes,
+// one per 8x8 quadrant of the tile.  A small splat reaches
+// one or two quadrants; walked in lock step the whole wave spends a pass (and a wave-wide reduction) on it.  Here lane l belongs
+// to quadrant g = l >> 4 and owns the pixels (i & 3 [+ 4], i >> 2 [+ 4]), i = l & 15, of it (two packed pairs), and each group walks
+// only the batch's entries whose mask has ITS bit: in one pass the wave works on up to four different splats, and one transposing
+// butterfly over the rows of 16 lanes (row_sum9_transpose) reduces all four.  The order inside a quadrant is the list's, which is
+// all the blend needs.  A group's totals are added to the entry's nine sums in LDS; when the batch is through, lane j forms entry
+// j's gradient row and stores it whole (48 B) - rows are written for every entry some group attempted (row_valid).
+// A batch ends when its slowest group does (measured imbalance over a frame: 1.01 .. 1.14, tools/quad_stats.py).
 __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, const uint2 *__restrict__ ranges,
                                                       const uint32_t *__restrict__ tile_walk,
                                                       const uint32_t *__restrict__ sorted_gid, const uint32_t *__restrict__ sorted_slot,
@@ -483,12 +441,12 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
                                                       const uint32_t *__restrict__ unit_count)
 {
     __shared__ float4 sh_rec[kWave * 3];
+    __shared__ float sh_acc[kWave * 9];          // the batch's sums, [entry][value]: stride 9 words, conflict-free by lane
 #ifdef GSR_BWD_TRACE
     TraceEnd trace_end{(unsigned long long)wall_clock64(), (int)blockIdx.x};
 #endif
-    // block b serves shard b % 8: its lists one after the other (full segments first, then the partial ones by length class)
     const int shard = (int)(blockIdx.x & (kUnitShards - 1));
-    uint32_t list_end[kUnitClasses];             // running ends of the lists in the shard's unit numbering (wave-uniform)
+    uint32_t list_end[kUnitClasses];
     {
         uint32_t run = 0;
 #pragma unroll
@@ -496,13 +454,16 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
     }
     const uint32_t n_units = list_end[kUnitClasses - 1];
     const size_t Tn = (size_t)f.Gx * f.Gy;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, grp = lane >> 4, gi = lane & 15;
     const size_t N = (size_t)f.W * f.H;
     const float half_w = 0.5f * (float)f.W, half_h = 0.5f * (float)f.H;
-    // where this lane's total of the wave reduction goes in a gradient row (store_rows below): float index, factor
-    const int h31 = lane & 31;
-    const int row_off = h31 == 8 ? 3 : h31 == 12 ? 4 : h31 == 16 ? 5 : h31 == 20 ? 6 : h31 == 24 ? 8 : -1;
-    const float row_mul = (h31 == 8 || h31 == 12) ? -0.5f : 1.f;
+    // where the butterfly leaves this lane's share of a group's totals: which value (of which register), if any
+    const int quad = (lane >> 2) & 3, in_quad = lane & 3;
+    const unsigned acc_idx = (unsigned)(in_quad == 0 ? (quad < 2 ? quad : quad + 2) : in_quad == 1 ? (quad < 2 ? quad + 2 : quad + 4) : 8);
+    const unsigned grp_shift = 8u * (unsigned)grp;
+    const bool acc_on = in_quad < 2 || (in_quad == 2 && quad == 0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sh_acc[lane * 9 + k] = 0.f;
     for (uint32_t u = blockIdx.x / kUnitShards; u < n_units; u += gridDim.x / kUnitShards) {
         int cls = 0;
         for (int k = 0; k < kUnitClasses - 1; ++k) cls += u >= list_end[k] ? 1 : 0;
@@ -510,32 +471,31 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
         const int tile = (int)(unit.x & ((1u << kUnitTileBits) - 1u)), c = (int)(unit.x >> kUnitTileBits);
         const int sgm = (int)unit.y;
         const int ty = tile / f.Gx, tx = tile - ty * f.Gx;
-        const int px0 = tx * GSR_TILE + lane_px(lane), py0 = ty * GSR_TILE + lane_py(lane);
-        const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 8.f;
+        const int lx = gi & 3, ly = gi >> 2;                                    // inside the quadrant; the other pixels are 4 further
+        const int px0 = tx * GSR_TILE + (grp & 1) * 8 + lx, py0 = ty * GSR_TILE + (grp >> 1) * 8 + ly;
+        const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 4.f;
         const uint2 rng = ranges[(size_t)c * Tn + tile];
         const int n_total = (int)(rng.y - rng.x);
         const int seg_begin = sgm * kSeg, seg_end = min(n_total, seg_begin + kSeg);
-        const int walk_end = min(seg_end, (int)tile_walk[(size_t)c * Tn + tile]);       // nothing behind it was composited in this chunk
+        const int walk_end = min(seg_end, (int)tile_walk[(size_t)c * Tn + tile]);
 
-        // Per-pixel state in PAIRS (the left and right quadrant of a tile half) as 2-vectors: the arithmetic compiles to packed
-        // fp32 instructions, two pixels per VALU issue.  A pixel takes part up to its own last contributor (all of the range for
-        // chunks before the one that holds it, nothing after).
         BwdPair P0, P1;
         const float *chk = (sgm > 0) ? ckpt + (size_t)((rng.x + (uint32_t)seg_begin) / kSeg) * kCkptFloats
                                      : (c > 0 ? ckpt_start + ((size_t)(c - 1) * Tn + tile) * kCkptFloats : nullptr);
-        auto load_px = [&](int k, float &Tk, float &Ek, float &r_, float &g_, float &b_, int &limit) {
-            const int px = px0 + (k & 1) * 8, py = py0 + (k >> 1) * 8;
+        auto load_px = [&](int e, float &Tk, float &Ek, float &r_, float &g_, float &b_, int &limit) {
+            const int ox = (e & 1) * 4, oy = (e >> 1) * 4;
+            const int px = px0 + ox, py = py0 + oy;
             const bool inside = px < f.W && py < f.H;
             const size_t pix = inside ? (size_t)py * f.W + px : 0;
             const int enc = inside ? last_enc[pix] : 0;
-            const int c_last = (enc >> kLastShift) - 1;                              // -1: no contributor at all
+            const int c_last = (enc >> kLastShift) - 1;
             limit = c < c_last ? n_total : (c == c_last ? (enc & ((1 << kLastShift) - 1)) : 0);
             r_ = inside ? dL_dpix[pix] : 0.f; g_ = inside ? dL_dpix[N + pix] : 0.f; b_ = inside ? dL_dpix[2 * N + pix] : 0.f;
-            // E = Q - D: the final pixel (background term included) minus the colour in front of the segment, dotted with dL/dpix
             float er = inside ? out_color[pix] : 0.f, eg = inside ? out_color[N + pix] : 0.f, eb = inside ? out_color[2 * N + pix] : 0.f;
             Tk = 1.f;
             if (chk) {
-                const float *q = chk + 4 * k * kWave + lane;
+                // the forward's checkpoint layout: [quadrant][T, r, g, b][its lane = (y << 3 | x) inside the quadrant]
+                const float *q = chk + 4 * grp * kWave + ((ly + oy) << 3 | (lx + ox));
                 Tk = q[0];
                 er -= q[kWave]; eg -= q[2 * kWave]; eb -= q[3 * kWave];
             }
@@ -548,104 +508,80 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
             load_px(2, Ta, Ea, ra, ga, bla, P1.limit0); load_px(3, Tb, Eb, rb, gb, blb, P1.limit1);
             P1.T = v2f{Ta, Tb}; P1.E = v2f{Ea, Eb}; P1.dpr = v2f{ra, rb}; P1.dpg = v2f{ga, gb}; P1.dpb = v2f{bla, blb};
         }
-        // per quadrant: the wave's last participating contributor
-        const int qmax0 = min(walk_end, wave_max_uniform(P0.limit0)), qmax1 = min(walk_end, wave_max_uniform(P0.limit1)),
-                  qmax2 = min(walk_end, wave_max_uniform(P1.limit0)), qmax3 = min(walk_end, wave_max_uniform(P1.limit1));
+        // per quadrant (= per group): its last participating contributor
+        int gmax = max(max(P0.limit0, P0.limit1), max(P1.limit0, P1.limit1));
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) gmax = max(gmax, __shfl_xor(gmax, off));
+        const int qmax0 = min(walk_end, __builtin_amdgcn_readlane(gmax, 0)), qmax1 = min(walk_end, __builtin_amdgcn_readlane(gmax, 16)),
+                  qmax2 = min(walk_end, __builtin_amdgcn_readlane(gmax, 32)), qmax3 = min(walk_end, __builtin_amdgcn_readlane(gmax, 48));
         const int max_contrib = max(max(qmax0, qmax1), max(qmax2, qmax3));
 
         for (int base = seg_begin; base < seg_end; base += kWave) {
-            if (base >= max_contrib) break;                    // nothing behind it was composited: those rows are never written
+            if (base >= max_contrib) break;
             const int n = min(kWave, seg_end - base);
-            const uint32_t slot = lane < n ? sorted_slot[rng.x + base + lane] : 0u;      // the instance's gradient row
-            {
-                __syncthreads();
-                unsigned mymask = stage_batch(sh_rec, lane, n, sorted_gid, rng.x + base, records);
-                __syncthreads();
-                // quadrants whose pixels all stopped before a splat take no part in it (contributor index = pos + 1)
-                const int mypos = base + lane;
-                mymask &= (mypos < qmax0 ? 1u : 0u) | (mypos < qmax1 ? 2u : 0u) | (mypos < qmax2 ? 4u : 0u) | (mypos < qmax3 ? 8u : 0u);
-                unsigned long long act = __ballot(mymask != 0u);       // splats with work, walked front to back
-                // One splat's pass over the tile: the lane's nine partial sums (both pairs, both pair elements added up).
-                // Returns false when no pixel of the tile accepted the splat (its row is not written).
-                auto splat_pass = [&](int j, float (&s)[9]) -> bool {
-                    const int pos = base + j;
-                    const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)mymask, j);
-                    const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
-                    BwdSplat sp;
-                    sp.lop = b.y; sp.cr = b.z; sp.cg = b.w; sp.cb = sh_rec[3 * j + 2].x;
-                    const float dxl = a.x - fx0;
-                    const v2f dx = {dxl, dxl - 8.f};
-                    const v2f axx = a.z * dx * dx + b.y, bx = a.w * dx;       // pre-scaled record: lp = log2(op exp(power))
-                    BwdAcc A;
-                    A.X = A.Y = A.S2 = A.S3 = A.S4 = A.S5 = A.S6 = A.S7 = A.S8 = v2f{0.f, 0.f};
-                    bool any_valid = false;
-                    if (m & 3u) {
-                        const float dy = a.y - fy0;
-                        any_valid = bwd_pair_dispatch(m & 3u, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P0, A);
-                    }
-                    if (m & 12u) {
-                        const float dy = a.y - fy1;
-                        const bool v = bwd_pair_dispatch(m >> 2, sp, (b.x * dy + bx) * dy + axx, dx, dy, pos, P1, A);
-                        any_valid = any_valid || v;
-                    }
-                    if (__ballot(any_valid) == 0ull) return false;
-                    // (nine plain adds: left to itself the compiler transposes the pairs with twelve moves to use packed adds)
-                    s[0] = add_halves(A.X); s[1] = add_halves(A.Y); s[2] = add_halves(A.S2); s[3] = add_halves(A.S3);
-                    s[4] = add_halves(A.S4); s[5] = add_halves(A.S5); s[6] = add_halves(A.S6); s[7] = add_halves(A.S7);
-                    s[8] = add_halves(A.S8);
-                    return true;
-                };
-                // Rows are stored by the lanes the reduction left the totals in (wave_sum9_two; h = lane & 31): h = 0 holds X, Y and S2
-                // and forms dL/dmean2D from the splat's record, which is still staged (the same batch); five more lanes hold one value
-                // each, h = 16 two.  -(X cA + Y cB) = ln2 (2 qA X + qB Y), likewise for y; gA, gB, gC carry the -1/2 of A.9.
-                auto store_rows = [&](const float (&s)[9], int j, uint32_t slot_j) {
-                    float *row = reinterpret_cast<float *>(grad_rows) + kRowFloats * (size_t)slot_j;
-                    const int h = lane & 31;
-                    if (h == 0) {
-                        const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
-                        const float gx = 2.f * a.z * s[0] + a.w * s[1], gy = 2.f * b.x * s[1] + a.w * s[0];
-                        row[0] = gx * (0.69314718f * half_w); row[1] = gy * (0.69314718f * half_h); row[2] = s[2] * -0.5f;
-                        row_valid[slot_j] = 1;                  // (cleared ahead of the launch; rows nobody writes are never read)
-                    } else if (row_off >= 0) {
-                        float v = s[0] * row_mul;
-                        if (h == 16) {
-                            v = s[0] * __builtin_amdgcn_exp2f(-sh_rec[3 * j + 1].y);       // dL/dopacity = sum(ga dL/dalpha) / opacity
-                            row[7] = s[2];
-                        }
-                        row[row_off] = v;
-                    }
-                };
-                // The accepted splats are reduced over the wave TWO at a time: v_permlane32_swap exchanges the upper half
-                // of the first splat's sums with the lower half of the second's, one add folds the halves, and the five
-                // remaining DPP steps run once for both (7 instructions per quantity for two splats instead of 12).  The
-                // first splat's totals land in lane 31, the second's in lane 63; each stores its own row.
-                while (act != 0ull) {
-                    float s1[9];
-                    int j1 = 0;
-                    bool have1 = false;
-                    while (act != 0ull && !have1) {
-                        j1 = __ffsll((long long)act) - 1;
-                        act &= act - 1ull;
-                        have1 = splat_pass(j1, s1);
-                    }
-                    if (!have1) break;
-                    float s2[9];
-                    int j2 = 0;
-                    bool have2 = false;
-                    while (act != 0ull && !have2) {
-                        j2 = __ffsll((long long)act) - 1;
-                        act &= act - 1ull;
-                        have2 = splat_pass(j2, s2);
-                    }
-                    if (!have2) {                              // the batch's odd splat out: the second half of the tree runs on zeros
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) s2[i] = 0.f;
-                    }
-                    wave_sum9_two(s1, s2);                     // first splat's totals in lanes 0..31, second's in 32..63
-                    const uint32_t slot1 = (uint32_t)__builtin_amdgcn_readlane((int)slot, j1);
-                    const uint32_t slot2 = (uint32_t)__builtin_amdgcn_readlane((int)slot, have2 ? j2 : j1);
-                    if (lane < 32 || have2) store_rows(s1, lane < 32 ? j1 : j2, lane < 32 ? slot1 : slot2);
+            const uint32_t slot = lane < n ? sorted_slot[rng.x + base + lane] : 0u;
+            __syncthreads();
+            unsigned mymask = stage_batch(sh_rec, lane, n, sorted_gid, rng.x + base, records);
+            __syncthreads();
+            const int mypos = base + lane;
+            mymask &= (mypos < qmax0 ? 1u : 0u) | (mypos < qmax1 ? 2u : 0u) | (mypos < qmax2 ? 4u : 0u) | (mypos < qmax3 ? 8u : 0u);
+            // the entries each group has to walk (wave-uniform bit sets: scalar registers)
+            unsigned long long act0 = __ballot((mymask & 1u) != 0u), act1 = __ballot((mymask & 2u) != 0u),
+                               act2 = __ballot((mymask & 4u) != 0u), act3 = __ballot((mymask & 8u) != 0u);
+            // a pixel's limit relative to the batch, clamped to [0, 64]: an idle group's entry number (255) fails it by itself
+            const int L00 = P0.limit0, L01 = P0.limit1, L10 = P1.limit0, L11 = P1.limit1;
+            P0.limit0 = min(max(L00 - base, 0), kWave); P0.limit1 = min(max(L01 - base, 0), kWave);
+            P1.limit0 = min(max(L10 - base, 0), kWave); P1.limit1 = min(max(L11 - base, 0), kWave);
+            while ((act0 | act1 | act2 | act3) != 0ull) {
+                // each group's next entry (255: it is through with the batch), one byte per group in a scalar register
+                const unsigned j0 = act0 ? (unsigned)__ffsll((long long)act0) - 1u : 255u, j1 = act1 ? (unsigned)__ffsll((long long)act1) - 1u : 255u,
+                               j2 = act2 ? (unsigned)__ffsll((long long)act2) - 1u : 255u, j3 = act3 ? (unsigned)__ffsll((long long)act3) - 1u : 255u;
+                act0 &= act0 - 1ull; act1 &= act1 - 1ull; act2 &= act2 - 1ull; act3 &= act3 - 1ull;      // (0 & anything = 0)
+                const unsigned jw = j0 | j1 << 8 | j2 << 16 | j3 << 24;
+                const unsigned j = __builtin_amdgcn_ubfe(jw, grp_shift, 8u);
+                const unsigned jj = j & (unsigned)(kWave - 1);
+                const float4 a = sh_rec[3u * jj], b = sh_rec[3u * jj + 1u];
+                const BwdSplat sp{b.y, b.z, b.w, sh_rec[3u * jj + 2u].x};
+                const float dxl = a.x - fx0;
+                const v2f dx = {dxl, dxl - 4.f};
+                const v2f axx = a.z * dx * dx + b.y, bx = a.w * dx;
+                BwdAcc A;
+                {
+                    const float dy = a.y - fy0;
+                    bwd_pair<true>(sp, (b.x * dy + bx) * dy + axx, dx, dy, (int)j, P0, A);
                 }
+                {
+                    const float dy = a.y - fy1;
+                    bwd_pair<false>(sp, (b.x * dy + bx) * dy + axx, dx, dy, (int)j, P1, A);
+                }
+                float s[9] = {add_halves(A.X), add_halves(A.Y), add_halves(A.S2), add_halves(A.S3), add_halves(A.S4), add_halves(A.S5),
+                              add_halves(A.S6), add_halves(A.S7), add_halves(A.S8)};
+                row_sum9_transpose(s);
+                const float mine = in_quad == 0 ? s[0] : in_quad == 1 ? s[2] : s[8];
+#if GSR_BWD_ORDERED_ADDS
+                // groups that meet on an entry in the same pass add in group order: one LDS instruction per group
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (acc_on && j < (unsigned)kWave && grp == k) atomicAdd(&sh_acc[jj * 9u + acc_idx], mine);
+#else
+                // (one instruction: the order in which the LDS serves lanes of different groups that meet on an entry is the hardware's)
+                if (acc_on && j < (unsigned)kWave) atomicAdd(&sh_acc[jj * 9u + acc_idx], mine);
+#endif
+            }
+            P0.limit0 = L00; P0.limit1 = L01; P1.limit0 = L10; P1.limit1 = L11;
+            __syncthreads();
+            if (mymask != 0u) {
+                float v[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { v[k] = sh_acc[lane * 9 + k]; sh_acc[lane * 9 + k] = 0.f; }
+                const float4 a = sh_rec[3 * lane], b = sh_rec[3 * lane + 1];
+                // -(X cA + Y cB) = ln2 (2 qA X + qB Y), likewise for y; gA, gB, gC carry the -1/2 of A.9; dL/dopacity = sum / opacity
+                const float gx = 2.f * a.z * v[0] + a.w * v[1], gy = 2.f * b.x * v[1] + a.w * v[0];
+                float4 *row = grad_rows + 3 * (size_t)slot;
+                row[0] = make_float4(gx * (0.69314718f * half_w), gy * (0.69314718f * half_h), v[2] * -0.5f, v[3] * -0.5f);
+                row[1] = make_float4(v[4] * -0.5f, v[5] * __builtin_amdgcn_exp2f(-b.y), v[6], v[7]);
+                row[2] = make_float4(v[8], 0.f, 0.f, 0.f);
+                row_valid[slot] = 1;
             }
         }
     }
