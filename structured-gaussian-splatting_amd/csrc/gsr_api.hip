@@ -9,6 +9,9 @@
 #include <vector>
 
 #include "gsr_internal.h"
+#ifndef GSR_FILL_BEFORE_WAIT
+#define GSR_FILL_BEFORE_WAIT 1
+#endif
 
 namespace gsr {
 
@@ -351,8 +354,10 @@ int gsr_forward_preprocess(const gsr_frame_desc *desc, const gsr_camera *cam, co
     return GSR_OK;
 }
 
-int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws, void *binning_ws,
-                       void *image_ws, gsr_frame_plan *plan, float *out_color, void *stream)
+// fill (optional): a zero fill to enqueue behind the FIRST chunk's blend and readback kernels, ahead of the wait for that readback
+// (gsr_forward's early fill); *fill_done reports whether it was enqueued
+static int forward_render_impl(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws, void *binning_ws,
+                               void *image_ws, gsr_frame_plan *plan, float *out_color, void *stream, const ZeroSegs *fill, bool *fill_done)
 {
     int rc = validate(desc);
     if (rc) return rc;
@@ -461,6 +466,11 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
         CtrlMirror mirror;
         if ((rc = next_mirror(&mirror))) return rc;
         if ((rc = launch_open_update(f, gw, iw, dbg, s, mirror))) return rc;
+        if (fill) {                                   // behind the kernel that posts the readback, ahead of the wait for it
+            ProfileScope prof("zero_outputs", s);
+            if ((rc = launch_zero_segments(*fill, s))) return rc;
+            *fill_done = true; fill = nullptr;
+        }
         Ctrl h;
         if ((rc = wait_ctrl(gw.ctrl, &h, s))) return rc;
         plan->instances_emitted = (int64_t)h.chunk_base[c + 1];
@@ -471,6 +481,13 @@ int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const 
     }
     plan->sort_result = sort_result;
     return GSR_OK;
+}
+
+int gsr_forward_render(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws, void *binning_ws,
+                       void *image_ws, gsr_frame_plan *plan, float *out_color, void *stream)
+{
+    bool unused = false;
+    return forward_render_impl(desc, cam, g, geom_ws, binning_ws, image_ws, plan, out_color, stream, nullptr, &unused);
 }
 
 int gsr_forward(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gaussians *g, void *geom_ws, void *image_ws, int32_t *radii,
@@ -487,13 +504,32 @@ int gsr_forward(const gsr_frame_desc *desc, const gsr_camera *cam, const gsr_gau
     }
     plan->binning_capacity = binning_capacity < plan->num_rendered ? binning_capacity : plan->num_rendered;
     if (plan->binning_capacity <= 0) plan->binning_capacity = 0;
-    if ((rc = gsr_forward_render(desc, cam, g, geom_ws, binning_ws, image_ws, plan, out_color, stream))) return rc;
-    if (early_fill && !early_fill->prezeroed && desc->P > 0 && plan->num_rendered > 0 && plan->chunks_run > 0 &&
-        effective_binned_ranks(*plan) * 4 < (long long)desc->P) {
-        const FrameK f = make_frame(*desc);
-        const BinningWS bw = carve_binning(binning_ws, plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered, f);
-        ProfileScope prof("zero_outputs", (hipStream_t)stream);
-        if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream, bw.row_valid, valid_bytes(plan)))) return rc;
+    // The early fill: the zeros of a depth-complex frame's gradient tensors + the blend backward's row flags, 50 us of HBM writes at
+    // 1M Gaussians.  It is enqueued behind the first chunk's blend and the kernel that posts its readback, BEFORE the host waits, so that it
+    // runs while the host is idle in the wait and then busy getting back to its caller and on to the next launch (~60 us in which the
+    // GPU has nothing else to do).  Whether the frame ends up sparse is only known after the readback: the fill is enqueued when the
+    // first planned chunk alone is sparse - a frame whose first chunk holds a quarter of the Gaussians takes the dense path whatever
+    // follows - and is wasted bandwidth, nothing more, when later chunks make the frame dense after all.  (Measured and dropped: the
+    // fill on a side stream beside the blend - the cross-queue waits cost more than it hid; the fill as the first job of every wave
+    // of the blend forward - 17 us there instead of 47, but the gap after the readback was empty again: 0.694 ms per step, not 0.678.)
+    const bool fill_wanted = early_fill && !early_fill->prezeroed && desc->P > 0 && plan->num_rendered > 0;
+    const FrameK f = make_frame(*desc);
+    ZeroSegs fill;
+    fill.n = 0;
+    bool filled = false;
+    if (GSR_FILL_BEFORE_WAIT && fill_wanted && plan->num_chunks > 1 && (long long)plan->chunk_rank_begin[1] * 4 < (long long)desc->P) {
+        const long long cap = plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered;
+        const BinningWS bw = carve_binning(binning_ws, cap, f);
+        fill = zero_segments(f, *g, nullptr, *early_fill, bw.row_valid, ((size_t)(cap < 1 ? 1 : cap) + 15) & ~(size_t)15);
+    }
+    if ((rc = forward_render_impl(desc, cam, g, geom_ws, binning_ws, image_ws, plan, out_color, stream, fill.n > 0 ? &fill : nullptr, &filled)))
+        return rc;
+    if (fill_wanted && plan->chunks_run > 0 && effective_binned_ranks(*plan) * 4 < (long long)desc->P) {
+        if (!filled) {
+            const BinningWS bw = carve_binning(binning_ws, plan->binning_capacity > 0 ? plan->binning_capacity : plan->num_rendered, f);
+            ProfileScope prof("zero_outputs", (hipStream_t)stream);
+            if ((rc = launch_zero_outputs(f, *g, nullptr, *early_fill, (hipStream_t)stream, bw.row_valid, valid_bytes(plan)))) return rc;
+        }
         early_fill->prezeroed = 1;
         plan->tile_order_ready = 1;                      // the fill also cleared the blend backward's row flags
     }

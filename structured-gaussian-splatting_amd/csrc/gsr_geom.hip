@@ -588,13 +588,6 @@ __global__ __launch_bounds__(kGeomBlock) void k_geom_bwd_sparse(FrameK f, int n_
 
 // ---- one launch that zero-fills up to nine output tensors (the sparse path's "memset"): the segments are laid end to
 // end in a virtual float index space; each thread clears a float4 where the 16 bytes lie inside one segment.
-struct ZeroSegs {
-    float *ptr[11];
-    size_t len[11];      // floats to clear in segment i
-    size_t end[11];     // exclusive end of segment i in the virtual index space (lengths rounded up to 4 floats)
-    int n;
-};
-
 __global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z)
 {
     const unsigned block = blockIdx.x, blocks = gridDim.x;
@@ -612,9 +605,7 @@ __global__ __launch_bounds__(kGeomBlock) void k_zero_segments(ZeroSegs z)
     }
 }
 
-// zero-fill of the backward's outputs in ONE launch: screen-space gradients (optional) + every wanted parameter gradient
-int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
-                        uint8_t *row_valid, size_t valid_bytes)
+ZeroSegs zero_segments(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, uint8_t *row_valid, size_t valid_bytes)
 {
     const size_t P = (size_t)f.P;
     ZeroSegs z;
@@ -633,6 +624,18 @@ int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, 
     if (g.shs) add(out.shs, P * 3 * (size_t)(split ? 1 : f.M));
     if (split && f.M > 1) add(out.shs_rest, P * 3 * (size_t)(f.M - 1));
     if (row_valid && valid_bytes) add(reinterpret_cast<float *>(row_valid), (valid_bytes + 3) / 4);     // (a 256-byte aligned, padded block)
+    return z;
+}
+
+// zero-fill of the backward's outputs in ONE launch: screen-space gradients (optional) + every wanted parameter gradient
+int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
+                        uint8_t *row_valid, size_t valid_bytes)
+{
+    return launch_zero_segments(zero_segments(f, g, screen, out, row_valid, valid_bytes), s);
+}
+
+int launch_zero_segments(const ZeroSegs &z, hipStream_t s)
+{
     if (z.n == 0) return GSR_OK;
     const size_t total = z.end[z.n - 1];
     size_t blocks = (total / 4 + kGeomBlock - 1) / kGeomBlock / 4 + 1;

@@ -239,12 +239,23 @@ int launch_chunk_binning(const FrameK &f, int c, int r0, int r1, uint64_t n_max,
                          ImageWS &iw,
                          int *sort_result, bool debug, hipStream_t s, bool filtered = false);
 int launch_open_update(const FrameK &f, GeomWS &gw, ImageWS &iw, bool debug, hipStream_t s, CtrlMirror mirror = CtrlMirror());
+// Zero fill of up to eleven arrays in one go (the sparse path's "memset"): the segments are laid end to end in a virtual float index
+// space (lengths rounded up to 4 floats).
+struct ZeroSegs {
+    float *ptr[11];
+    size_t len[11];      // floats to clear in segment i
+    size_t end[11];      // exclusive end of segment i in the virtual index space
+    int n;
+};
+ZeroSegs zero_segments(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, uint8_t *row_valid = nullptr,
+                       size_t valid_bytes = 0);
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, int sort_result, const GeomWS &gw, const BinningWS &bw,
                       ImageWS &iw, float *out_color, bool debug, hipStream_t s);
 // rows_upper: bound of the instances the chunks that ran emitted (sizes the launch: the unit count lives on the device)
 int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long long rows_upper, const GeomWS &gw, BinningWS &bw,
                       const ImageWS &iw, const float *out_color, const float *dL_dcolor, bool debug, hipStream_t s);
 // row_valid / valid_bytes: also clear that many bytes of the blend backward's row-valid flags
+int launch_zero_segments(const ZeroSegs &z, hipStream_t s);
 int launch_zero_outputs(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, hipStream_t s,
                         uint8_t *row_valid = nullptr, size_t valid_bytes = 0);
 int launch_reduce_rows(const FrameK &f, const gsr_frame_plan &plan, const GeomWS &gw, const BinningWS &bw, float *screen_grads,
