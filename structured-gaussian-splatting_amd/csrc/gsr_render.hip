@@ -539,7 +539,8 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
                 act0 &= act0 - 1ull; act1 &= act1 - 1ull; act2 &= act2 - 1ull; act3 &= act3 - 1ull;      // (0 & anything = 0)
                 const unsigned jw = j0 | j1 << 8 | j2 << 16 | j3 << 24;
                 const unsigned j = __builtin_amdgcn_ubfe(jw, grp_shift, 8u);
-                const unsigned jj = j & (unsigned)(kWave - 1);
+                const unsigned jj = j < (unsigned)kWave ? j : 0u;       // (an idle group reads the batch's first record: staged for sure,
+                                                                         // where the slots behind a short batch's end hold whatever LDS held)
                 const float4 a = sh_rec[3u * jj], b = sh_rec[3u * jj + 1u];
                 const BwdSplat sp{b.y, b.z, b.w, sh_rec[3u * jj + 2u].x};
                 const float dxl = a.x - fx0;
