@@ -99,9 +99,10 @@ def algorithmic_bytes(P, V, Vb, Re, N, Tn, K, M, Vlive, sparse_geom, prezeroed, 
         # K6: id 4 + record 36 per instance; 20 B/px; per tile its walked depth and its work units out; one 4 KB checkpoint per
         # kSeg = 128 walked entries (32 B per walked instance)
         "render_fwd": 40 * Re + 20 * N + 12 * Tn + 32 * walked,
-        # K7 (front to back, one wave per work unit): 40 read + 36 written per walked instance (an upper bound for the rows: only
-        # splats some pixel accepts are written); per unit the 256 pixels' 32 B (T, last, dL/dpix, final colour) + its 16 B/px checkpoint
-        "render_bwd": 76 * walked + 256 * 48 * units,
+        # K7 (front to back, one wave per work unit): 40 read + one whole 48-byte row written per walked instance (an upper bound for the
+        # rows: the entries no quadrant group attempted are not written); per unit the 256 pixels' 32 B (T, last, dL/dpix, final colour)
+        # + its 16 B/px checkpoint
+        "render_bwd": 88 * walked + 256 * 48 * units,
         "reduce_rows": Re + 36 * walked + 36 * Vb,          # deterministic reduction (replaces atomic RMW): a valid byte per row, written rows only
         "geom_bwd": 4 * geom_rows + (99 + 12 * K) * Vlive + (40 + 12 * M) * geom_written,        # K8 + K9
         "loss_fwd": 20 * C * N, "loss_bwd": 24 * C * N,
