@@ -155,6 +155,7 @@ constexpr double kReadbackTimeoutS = 30.0;
 // experiment switches (tools/): read ONCE, when the library is loaded — a re-run of gsr_forward_render after GSR_ERR_WORKSPACE must
 // take the decisions of the first run, whatever the environment does in between
 static const bool kNoLiveFilter = getenv("GSR_NO_LIVE_FILTER") != nullptr, kNoChunkMerge = getenv("GSR_NO_CHUNK_MERGE") != nullptr;
+static const int kFwdGroups = getenv("GSR_FWD_GROUPS") ? atoi(getenv("GSR_FWD_GROUPS")) : -1;       // 0 / 1: force the blend forward's kernel
 
 static inline void cpu_pause()
 {
@@ -459,7 +460,10 @@ static int forward_render_impl(const gsr_frame_desc *desc, const gsr_camera *cam
                                        (plan->chunks_filtered >> c) & 1)))
             return rc;
         if ((rc = launch_chunk_colors(f, *cam, *g, r0, r1, plan->num_visible, gw, dbg, s))) return rc;      // A.6 for this chunk's Gaussians only
-        if ((rc = launch_render_fwd(f, *cam, c, last, sort_result, gw, bw, iw, out_color, dbg, s))) return rc;
+        // small splats (fewer than 4.5 tiles per Gaussian on average; filtered chunks bin a small, unknown part of their bound):
+        // the blend forward with one 16-lane group per quadrant
+        const bool small_splats = kFwdGroups >= 0 ? kFwdGroups != 0 : (!((plan->chunks_filtered >> c) & 1) && chunk_n > 0 && chunk_max * 2 < chunk_n * 9);
+        if ((rc = launch_render_fwd(f, *cam, c, last, sort_result, gw, bw, iw, out_color, dbg, s, small_splats))) return rc;
         plan->chunks_run = c + 1;
         plan->instances_emitted = -1;                 // the last chunk's count stays on the device
         if (last) break;

@@ -249,8 +249,9 @@ struct ZeroSegs {
 };
 ZeroSegs zero_segments(const FrameK &f, const gsr_gaussians &g, float *screen, const gsr_grads &out, uint8_t *row_valid = nullptr,
                        size_t valid_bytes = 0);
+// groups: the chunk's splats are small (fewer than 4.5 tiles per Gaussian): the quadrant-group kernel (gsr_render.hip)
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, int sort_result, const GeomWS &gw, const BinningWS &bw,
-                      ImageWS &iw, float *out_color, bool debug, hipStream_t s);
+                      ImageWS &iw, float *out_color, bool debug, hipStream_t s, bool groups = false);
 // rows_upper: bound of the instances the chunks that ran emitted (sizes the launch: the unit count lives on the device)
 int launch_render_bwd(const FrameK &f, int chunks_run, int sort_result, long long rows_upper, const GeomWS &gw, BinningWS &bw,
                       const ImageWS &iw, const float *out_color, const float *dL_dcolor, bool debug, hipStream_t s);

@@ -77,6 +77,28 @@ typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 opera
 __device__ __forceinline__ int lane_px(int lane) { return lane & 7; }
 __device__ __forceinline__ int lane_py(int lane) { return lane >> 3; }
 
+// lp = log2(opacity exp(power)) of a pair of pixels from the pre-scaled record (qA, qB, qC = a.z, a.w, b.x; log2 opacity = b.y):
+//     lp = qA dx^2 + qB dx dy + qC dy^2 + lop = ((qC dy + qB dx) dy) + (qA dx) dx + lop
+// ONE definition for the three blend kernels, with every rounding spelled out (no contraction left to the compiler): the forward
+// kernels and the backward then agree on every pixel's lp - and with it on alpha, on the accept / stop decisions and on the
+// transmittance - bit for bit, whichever kernel rendered the frame.
+struct LpTerms { v2f axx, bx; };
+__device__ __forceinline__ LpTerms lp_terms(float qA, float qB, float lop, v2f dx)
+{
+#pragma clang fp contract(off)
+    LpTerms t;
+    const v2f adx = qA * dx;                                               // rounded
+    t.axx = __builtin_elementwise_fma(adx, dx, v2f{lop, lop});             // (qA dx) dx + lop
+    t.bx = qB * dx;                                                        // rounded
+    return t;
+}
+__device__ __forceinline__ v2f lp_at(const LpTerms &t, float qC, float dy)
+{
+#pragma clang fp contract(off)
+    const v2f s = __builtin_elementwise_fma(v2f{qC, qC}, v2f{dy, dy}, t.bx);        // qC dy + qB dx
+    return __builtin_elementwise_fma(s, v2f{dy, dy}, t.axx);
+}
+
 // Stage up to 64 records (one per lane) of a tile's list into LDS; returns the lane's quadrant mask (bits 28..31 of the
 // sorted list's entry, put there by the emit kernels: gsr_binning.hip).
 __device__ __forceinline__ unsigned stage_batch(float4 *sh_rec, int lane, int n, const uint32_t *__restrict__ sorted_gid, uint32_t first,
@@ -115,45 +137,25 @@ struct FwdPair {             // state of a lane's two pixels in one pair of quad
 
 // One register per pixel carries both "live transmittance" and "final transmittance of a done pixel": for a done pixel
 // test_T = T (1 - alpha) is negative, so the stop test fires by itself, nothing is composited and T keeps its value.
-template <int MODE>          // 3: both quadrants of the pair (packed), 1: the left one only, 2: the right one only
-__device__ __forceinline__ void fwd_pair(v2f lp, float lop, float cr, float cg, float cb, int contributor, FwdPair &P)
+// ONE definition for both forward kernels (active: the lane's group has a splat in this pass - always, in the lock-step kernel).
+__device__ __forceinline__ void fwd_pair(bool active, v2f lp, float lop, float cr, float cg, float cb, int contributor, FwdPair &P)
 {
-    if constexpr (MODE == 3) {
-        const bool keep0 = !(lp[0] > lop) && !(lp[0] < kLog2AlphaMin);      // power > 0  <=>  lp > lop;  alpha < 1/255  <=>  lp < log2(1/255)
-        const bool keep1 = !(lp[1] > lop) && !(lp[1] < kLog2AlphaMin);
-        // a rejected pixel gets lp = -inf: exp2 gives alpha = 0 by itself (one select per pixel, in front of the exponential)
-        const v2f ae = {fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep0 ? lp[0] : -INFINITY)),
-                        fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep1 ? lp[1] : -INFINITY))};
-        const v2f test_T = P.T * (1.f - ae);                       // == T when rejected, negative when already done
-        const v2f aT = ae * P.T;
-        const bool stop0 = test_T[0] < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
-        const bool stop1 = test_T[1] < (float)GSR_T_CUTOFF;
-        const v2f w = {stop0 ? 0.f : aT[0], stop1 ? 0.f : aT[1]};  // the stopping splat is NOT composited (A.8)
-        P.Cr += cr * w; P.Cg += cg * w; P.Cb += cb * w;
-        P.T = v2f{stop0 ? -fabsf(P.T[0]) : test_T[0], stop1 ? -fabsf(P.T[1]) : test_T[1]};
-        P.last0 = (keep0 && !stop0) ? contributor : P.last0;
-        P.last1 = (keep1 && !stop1) ? contributor : P.last1;
-    } else {
-        constexpr int e = MODE - 1;
-        const bool keep = !(lp[e] > lop) && !(lp[e] < kLog2AlphaMin);
-        const float ae = fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep ? lp[e] : -INFINITY));
-        const float test_T = P.T[e] * (1.f - ae);
-        const bool stop = test_T < (float)GSR_T_CUTOFF;
-        const float w = stop ? 0.f : ae * P.T[e];
-        P.Cr[e] += cr * w; P.Cg[e] += cg * w; P.Cb[e] += cb * w;
-        P.T[e] = stop ? -fabsf(P.T[e]) : test_T;
-        if constexpr (e == 0) P.last0 = (keep && !stop) ? contributor : P.last0;
-        else P.last1 = (keep && !stop) ? contributor : P.last1;
-    }
-}
-
-__device__ __forceinline__ void fwd_pair_dispatch(unsigned mp, v2f lp, float lop, float cr, float cg, float cb, int contributor, FwdPair &P)
-{
-#ifdef GSR_FWD_SINGLE
-    if (mp == 1u) { fwd_pair<1>(lp, lop, cr, cg, cb, contributor, P); return; }
-    if (mp == 2u) { fwd_pair<2>(lp, lop, cr, cg, cb, contributor, P); return; }
-#endif
-    fwd_pair<3>(lp, lop, cr, cg, cb, contributor, P);      // a clear mask bit / a dead quadrant rejects on its own (the backward does the same)
+    const bool keep0 = active && !(lp[0] > lop) && !(lp[0] < kLog2AlphaMin);      // power > 0  <=>  lp > lop;  alpha < 1/255  <=>  lp < log2(1/255)
+    const bool keep1 = active && !(lp[1] > lop) && !(lp[1] < kLog2AlphaMin);
+    // a rejected pixel gets lp = -inf: exp2 gives alpha = 0 by itself (one select per pixel, in front of the exponential)
+    const v2f ae = {fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep0 ? lp[0] : -INFINITY)),
+                    fminf((float)GSR_ALPHA_MAX, __builtin_amdgcn_exp2f(keep1 ? lp[1] : -INFINITY))};
+    const v2f test_T = P.T * (1.f - ae);                       // == T when rejected, negative when already done
+    const v2f aT = ae * P.T;
+    const bool stop0 = test_T[0] < (float)GSR_T_CUTOFF;        // live + accepted + below the cut-off, or done
+    const bool stop1 = test_T[1] < (float)GSR_T_CUTOFF;
+    const v2f w = {stop0 ? 0.f : aT[0], stop1 ? 0.f : aT[1]};  // the stopping splat is NOT composited (A.8)
+    P.Cr = __builtin_elementwise_fma(v2f{cr, cr}, w, P.Cr);
+    P.Cg = __builtin_elementwise_fma(v2f{cg, cg}, w, P.Cg);
+    P.Cb = __builtin_elementwise_fma(v2f{cb, cb}, w, P.Cb);
+    P.T = v2f{stop0 ? -fabsf(P.T[0]) : test_T[0], stop1 ? -fabsf(P.T[1]) : test_T[1]};
+    P.last0 = (keep0 && !stop0) ? contributor : P.last0;
+    P.last1 = (keep1 && !stop1) ? contributor : P.last1;
 }
 
 // wave-uniform 4-bit mask: quadrant k still has a live pixel
@@ -186,6 +188,34 @@ struct TraceEnd {
     }
 };
 #endif
+
+// the end of a (tile, chunk)'s blend: the tile's open flag, how deep the backward will walk, and the backward's work units
+__device__ __forceinline__ void fwd_tile_epilogue(int t, int tile, int c, int lane, bool closing, bool stuck, int walked, uint32_t *__restrict__ open,
+                                                  uint32_t *__restrict__ tile_walk_c, const UnitLists &units, uint32_t *__restrict__ unit_count)
+{
+    if (lane == 0) {
+        open[tile] = closing ? 0u : (stuck ? 2u : 1u);
+        tile_walk_c[tile] = (uint32_t)walked;
+    }
+    // the blend backward's work units of this (tile, chunk): one per kSeg walked entries, appended to the lists of the tile's shard
+    // (full segments; the last, partial one by its length class)
+    const uint32_t n_full = (uint32_t)walked / kSeg, rest = (uint32_t)walked - n_full * kSeg;
+    if (walked > 0) {
+        const int shard = t & (kUnitShards - 1);
+        const uint32_t head = (uint32_t)tile | ((uint32_t)c << kUnitTileBits);
+        const int cls = unit_class(rest);
+        uint32_t at_full = 0, at_part = 0;
+        if (lane == 0) {
+            if (n_full) at_full = atomicAdd(&unit_count[shard * kUnitClasses], n_full);
+            if (rest) at_part = atomicAdd(&unit_count[shard * kUnitClasses + cls], 1u);
+        }
+        at_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)at_full);
+        uint2 *full = units.units + units.list_begin(shard, 0);
+        for (uint32_t sgm = (uint32_t)lane; sgm < n_full; sgm += kWave)
+            if (at_full + sgm < units.cap_full) full[at_full + sgm] = make_uint2(head, sgm);
+        if (lane == 0 && rest && at_part < units.cap_part) units.units[units.list_begin(shard, cls) + at_part] = make_uint2(head, n_full);
+    }
+}
 
 __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, int n_tiles, int c, int finalize_all,
                                                       const uint2 *__restrict__ ranges_c, uint32_t *__restrict__ open,
@@ -263,14 +293,14 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
             const int contributor = enc_base | (base + j + 1);
             const float dxl = a.x - fx0;
             const v2f dx = {dxl, dxl - 8.f};
-            const v2f axx = a.z * dx * dx + b.y, bx = a.w * dx;       // record is pre-scaled: lp = log2(op exp(power))
+            const LpTerms lt = lp_terms(a.z, a.w, b.y, dx);
             if (m & 3u) {
                 const float dy = a.y - fy0;
-                fwd_pair_dispatch(m & 3u, (b.x * dy + bx) * dy + axx, b.y, b.z, b.w, cbl, contributor, P0);
+                fwd_pair(true, lp_at(lt, b.x, dy), b.y, b.z, b.w, cbl, contributor, P0);
             }
             if (m & 12u) {
                 const float dy = a.y - fy1;
-                fwd_pair_dispatch(m >> 2, (b.x * dy + bx) * dy + axx, b.y, b.z, b.w, cbl, contributor, P1);
+                fwd_pair(true, lp_at(lt, b.x, dy), b.y, b.z, b.w, cbl, contributor, P1);
             }
             if (++since_refresh == 8) {       // every 8 blended splats: quadrants (and tiles) that saturate mid-batch stop there
                 since_refresh = 0;
@@ -305,38 +335,155 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     // what the backward's wave will walk of this chunk's range: up to the tile's deepest contributor (launch order of K7)
     auto depth_here = [&](int last) { return (last >> kLastShift) == c + 1 ? (last & ((1 << kLastShift) - 1)) : 0; };
     const int walked = wave_max_uniform(max(max(depth_here(P0.last0), depth_here(P0.last1)), max(depth_here(P1.last0), depth_here(P1.last1))));
-    if (lane == 0) {
-        open[tile] = closing ? 0u : (stuck ? 2u : 1u);
-        tile_walk_c[tile] = (uint32_t)walked;
-    }
-    // the blend backward's work units of this (tile, chunk): one per kSeg walked entries, appended to the lists of the tile's shard
-    // (full segments; the last, partial one by its length class)
-    const uint32_t n_full = (uint32_t)walked / kSeg, rest = (uint32_t)walked - n_full * kSeg;
-    if (walked > 0) {
-        const int shard = t & (kUnitShards - 1);
-        const uint32_t head = (uint32_t)tile | ((uint32_t)c << kUnitTileBits);
-        const int cls = unit_class(rest);
-        uint32_t at_full = 0, at_part = 0;
-        if (lane == 0) {
-            if (n_full) at_full = atomicAdd(&unit_count[shard * kUnitClasses], n_full);
-            if (rest) at_part = atomicAdd(&unit_count[shard * kUnitClasses + cls], 1u);
+    fwd_tile_epilogue(t, tile, c, lane, closing, stuck, walked, open, tile_walk_c, units, unit_count);
+}
+
+// ---- The same blend with the wave split into four GROUPS of 16 lanes, one per quadrant (the mapping and the walk of k_render_bwd):
+// for chunks of SMALL splats (launch_render_fwd's `groups`: fewer than 4.5 tiles per Gaussian).  A splat that reaches one or two
+// quadrants costs the lock-step kernel a pass of the whole wave; here up to four different splats share a pass.  Where splats reach
+// most quadrants the lock-step kernel is faster (wave-uniform records, whole pairs skipped): cfg3n 258 -> 230 us with groups, but
+// cfg3 105 -> 116, cfg5n 696 -> 706 - hence two kernels.  The checkpoints and every per-pixel array are the same either way.
+// per 16-lane group (= quadrant): does it still hold a live pixel?  One ballot; bit g of the result = group g
+__device__ __forceinline__ unsigned live_groups(const FwdPair &A, const FwdPair &B)
+{
+    const unsigned long long bal = __ballot(A.T[0] > 0.f || A.T[1] > 0.f || B.T[0] > 0.f || B.T[1] > 0.f);
+    return ((bal & 0xFFFFull) ? 1u : 0u) | ((bal & 0xFFFF0000ull) ? 2u : 0u) | ((bal & 0xFFFF00000000ull) ? 4u : 0u) |
+           ((bal & 0xFFFF000000000000ull) ? 8u : 0u);
+}
+
+__global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd_groups(FrameK f, int n_tiles, int c, int finalize_all,
+                                                      const uint2 *__restrict__ ranges_c, uint32_t *__restrict__ open,
+                                                      const uint32_t *__restrict__ sorted_gid,
+                                                      const float4 *__restrict__ records, const float *__restrict__ bg,
+                                                      float *__restrict__ out_color, float *__restrict__ T_state,
+                                                      int32_t *__restrict__ last_enc, uint32_t *__restrict__ tile_walk_c,
+                                                      float *__restrict__ ckpt, float *__restrict__ ckpt_start_c,
+                                                      UnitLists units, uint32_t *__restrict__ unit_count)
+{
+    __shared__ float4 sh_rec[kWave * 3];
+    const int t = (int)blockIdx.x;
+    const int tx = t % f.Gx, ty = f.ty0 + t / f.Gx;
+    const int tile = ty * f.Gx + tx;
+    if (open[tile] == 0u) return;                       // closed by an earlier chunk: pixels are final
+    const uint2 rng = ranges_c[tile];
+    const int lane = threadIdx.x, grp = lane >> 4, gi = lane & 15;
+    const int lx = gi & 3, ly = gi >> 2;                                                  // inside the quadrant; the other pixels are 4 further
+    const int px0 = tx * GSR_TILE + (grp & 1) * 8 + lx, py0 = ty * GSR_TILE + (grp >> 1) * 8 + ly;
+    // dx is formed exactly as k_render_fwd forms it - (x_splat - x of the pixel's twin in the LEFT quadrant) - 8 for a right quadrant -
+    // so that the two kernels (and the backward) agree on every pixel's alpha bit for bit
+    const v2f fxl = {(float)(tx * GSR_TILE + lx), (float)(tx * GSR_TILE + lx + 4)};
+    const float qoff = (grp & 1) ? 8.f : 0.f;
+    const float fy0 = (float)py0, fy1 = fy0 + 4.f;
+    const size_t N = (size_t)f.W * f.H;
+    const unsigned grp_shift = 8u * (unsigned)grp;
+
+    FwdPair P0, P1;
+    auto load_px = [&](int e, float &t_, float &r_, float &g_, float &b_, int &last) {
+        const int px = px0 + (e & 1) * 4, py = py0 + (e >> 1) * 4;
+        const bool inside = px < f.W && py < f.H;
+        t_ = inside ? 1.f : -1.f; r_ = g_ = b_ = 0.f; last = 0;
+        if (c > 0 && inside) {
+            const size_t pix = (size_t)py * f.W + px;
+            t_ = T_state[pix];
+            r_ = out_color[pix]; g_ = out_color[N + pix]; b_ = out_color[2 * N + pix];
+            last = last_enc[pix];
         }
-        at_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)at_full);
-        uint2 *full = units.units + units.list_begin(shard, 0);
-        for (uint32_t sgm = (uint32_t)lane; sgm < n_full; sgm += kWave)
-            if (at_full + sgm < units.cap_full) full[at_full + sgm] = make_uint2(head, sgm);
-        if (lane == 0 && rest && at_part < units.cap_part) units.units[units.list_begin(shard, cls) + at_part] = make_uint2(head, n_full);
+    };
+    {
+        float t0, r0, g0, b0, t1, r1, g1, b1;
+        load_px(0, t0, r0, g0, b0, P0.last0); load_px(1, t1, r1, g1, b1, P0.last1);
+        P0.T = v2f{t0, t1}; P0.Cr = v2f{r0, r1}; P0.Cg = v2f{g0, g1}; P0.Cb = v2f{b0, b1};
+        load_px(2, t0, r0, g0, b0, P1.last0); load_px(3, t1, r1, g1, b1, P1.last1);
+        P1.T = v2f{t0, t1}; P1.Cr = v2f{r0, r1}; P1.Cg = v2f{g0, g1}; P1.Cb = v2f{b0, b1};
     }
+
+    const int n_total = (int)(rng.y - rng.x);
+    const int enc_base = (c + 1) << kLastShift;
+    // checkpoints in the layout k_render_fwd writes: [quadrant][T, r, g, b][y << 3 | x inside the quadrant]
+    auto checkpoint = [&](float *dst) {
+        float *q = dst + 4 * grp * kWave + (ly << 3 | lx);
+        q[0] = P0.T[0]; q[kWave] = P0.Cr[0]; q[2 * kWave] = P0.Cg[0]; q[3 * kWave] = P0.Cb[0];
+        q[4] = P0.T[1]; q[kWave + 4] = P0.Cr[1]; q[2 * kWave + 4] = P0.Cg[1]; q[3 * kWave + 4] = P0.Cb[1];
+        q[32] = P1.T[0]; q[kWave + 32] = P1.Cr[0]; q[2 * kWave + 32] = P1.Cg[0]; q[3 * kWave + 32] = P1.Cb[0];
+        q[36] = P1.T[1]; q[kWave + 36] = P1.Cr[1]; q[2 * kWave + 36] = P1.Cg[1]; q[3 * kWave + 36] = P1.Cb[1];
+    };
+    if (c > 0 && n_total > 0) checkpoint(ckpt_start_c + (size_t)tile * kCkptFloats);
+    for (int base = 0; base < n_total; base += kWave) {
+        unsigned live = live_groups(P0, P1);
+        if (live == 0u) break;
+        if (base > 0 && base % kSeg == 0) checkpoint(ckpt + (size_t)((rng.x + (uint32_t)base) / kSeg) * kCkptFloats);
+        const int n = min(kWave, n_total - base);
+        __syncthreads();
+        const unsigned mymask = stage_batch(sh_rec, lane, n, sorted_gid, rng.x + base, records);
+        __syncthreads();
+        // each group walks the batch's entries that reach ITS quadrant, front to back, while the quadrant holds a live pixel
+        unsigned long long act0 = (live & 1u) ? __ballot((mymask & 1u) != 0u) : 0ull, act1 = (live & 2u) ? __ballot((mymask & 2u) != 0u) : 0ull,
+                           act2 = (live & 4u) ? __ballot((mymask & 4u) != 0u) : 0ull, act3 = (live & 8u) ? __ballot((mymask & 8u) != 0u) : 0ull;
+        int since_refresh = 0;
+        while ((act0 | act1 | act2 | act3) != 0ull) {
+            const unsigned j0 = act0 ? (unsigned)__ffsll((long long)act0) - 1u : 255u, j1 = act1 ? (unsigned)__ffsll((long long)act1) - 1u : 255u,
+                           j2 = act2 ? (unsigned)__ffsll((long long)act2) - 1u : 255u, j3 = act3 ? (unsigned)__ffsll((long long)act3) - 1u : 255u;
+            act0 &= act0 - 1ull; act1 &= act1 - 1ull; act2 &= act2 - 1ull; act3 &= act3 - 1ull;
+            const unsigned j = __builtin_amdgcn_ubfe(j0 | j1 << 8 | j2 << 16 | j3 << 24, grp_shift, 8u);      // 255: the group idles
+            const bool active = j < (unsigned)kWave;
+            const unsigned jj = active ? j : 0u;                       // (an idle group reads the batch's first record: staged for sure)
+            const float4 a = sh_rec[3u * jj], b = sh_rec[3u * jj + 1u];
+            const float cbl = sh_rec[3u * jj + 2u].x;
+            const int contributor = enc_base | (int)((unsigned)base + jj + 1u);
+            const v2f dx = (a.x - fxl) - qoff;
+            const LpTerms lt = lp_terms(a.z, a.w, b.y, dx);
+            {
+                const float dy = a.y - fy0;
+                fwd_pair(active, lp_at(lt, b.x, dy), b.y, b.z, b.w, cbl, contributor, P0);
+            }
+            {
+                const float dy = a.y - fy1;
+                fwd_pair(active, lp_at(lt, b.x, dy), b.y, b.z, b.w, cbl, contributor, P1);
+            }
+            if (++since_refresh == 8) {       // every 8 passes: quadrants (and tiles) that saturate mid-batch stop there
+                since_refresh = 0;
+                live = live_groups(P0, P1);
+                if (!(live & 1u)) act0 = 0ull;
+                if (!(live & 2u)) act1 = 0ull;
+                if (!(live & 4u)) act2 = 0ull;
+                if (!(live & 8u)) act3 = 0ull;
+            }
+        }
+    }
+    const bool closing = live_groups(P0, P1) == 0u;
+    const bool finalize = closing || finalize_all != 0;
+    const float bg0 = finalize ? bg[0] : 0.f, bg1 = finalize ? bg[1] : 0.f, bg2 = finalize ? bg[2] : 0.f;
+    auto store_px = [&](int e, float t_, float r_, float g_, float b_, int last) {
+        const int px = px0 + (e & 1) * 4, py = py0 + (e >> 1) * 4;
+        if (px < f.W && py < f.H) {
+            const size_t pix = (size_t)py * f.W + px;
+            const float tf = fabsf(t_);
+            out_color[pix] = r_ + tf * bg0;
+            out_color[N + pix] = g_ + tf * bg1;
+            out_color[2 * N + pix] = b_ + tf * bg2;
+            T_state[pix] = t_;
+            last_enc[pix] = last;
+        }
+    };
+    store_px(0, P0.T[0], P0.Cr[0], P0.Cg[0], P0.Cb[0], P0.last0);
+    store_px(1, P0.T[1], P0.Cr[1], P0.Cg[1], P0.Cb[1], P0.last1);
+    store_px(2, P1.T[0], P1.Cr[0], P1.Cg[0], P1.Cb[0], P1.last0);
+    store_px(3, P1.T[1], P1.Cr[1], P1.Cg[1], P1.Cb[1], P1.last1);
+    auto clear_px = [&](int e, float t_) { return px0 + (e & 1) * 4 < f.W && py0 + (e >> 1) * 4 < f.H && t_ > 0.5f; };
+    const bool stuck = __ballot(clear_px(0, P0.T[0]) || clear_px(1, P0.T[1]) || clear_px(2, P1.T[0]) || clear_px(3, P1.T[1])) != 0ull;
+    auto depth_here = [&](int last) { return (last >> kLastShift) == c + 1 ? (last & ((1 << kLastShift) - 1)) : 0; };
+    const int walked = wave_max_uniform(max(max(depth_here(P0.last0), depth_here(P0.last1)), max(depth_here(P1.last0), depth_here(P1.last1))));
+    fwd_tile_epilogue(t, tile, c, lane, closing, stuck, walked, open, tile_walk_c, units, unit_count);
 }
 
 int launch_render_fwd(const FrameK &f, const gsr_camera &cam, int c, bool last_chunk, int sort_result, const GeomWS &gw, const BinningWS &bw,
-                      ImageWS &iw, float *out_color, bool debug, hipStream_t s)
+                      ImageWS &iw, float *out_color, bool debug, hipStream_t s, bool groups)
 {
     const int n_tiles = (f.ty1 - f.ty0) * f.Gx;
     if (n_tiles <= 0) return GSR_OK;
     ProfileScope prof("render_fwd", s);
     const size_t Tn = (size_t)f.Gx * f.Gy;
-    hipLaunchKernelGGL(k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, c, last_chunk ? 1 : 0,
+    hipLaunchKernelGGL(groups ? k_render_fwd_groups : k_render_fwd, dim3(n_tiles), dim3(kWave), 0, s, f, n_tiles, c, last_chunk ? 1 : 0,
                        iw.ranges + (size_t)c * Tn, iw.open, bw.gids[1], gw.records, cam.bg, out_color, iw.T_state,
                        iw.last_enc, iw.tile_walk + (size_t)c * Tn, bw.ckpt,
                        c > 0 ? iw.ckpt_start + (size_t)(c - 1) * Tn * kCkptFloats : nullptr, bw.units, iw.unit_count);
@@ -473,7 +620,11 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
         const int ty = tile / f.Gx, tx = tile - ty * f.Gx;
         const int lx = gi & 3, ly = gi >> 2;                                    // inside the quadrant; the other pixels are 4 further
         const int px0 = tx * GSR_TILE + (grp & 1) * 8 + lx, py0 = ty * GSR_TILE + (grp >> 1) * 8 + ly;
-        const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 4.f;
+        // dx exactly as the forward forms it: (x_splat - x of the pixel's twin in the LEFT quadrant) - 8 for a right quadrant; dy is one
+        // subtraction from the pixel's y either way: every pixel's lp, alpha and transmittance are the forward's, bit for bit
+        const v2f fxl = {(float)(tx * GSR_TILE + lx), (float)(tx * GSR_TILE + lx + 4)};
+        const float qoff = (grp & 1) ? 8.f : 0.f;
+        const float fy0 = (float)py0, fy1 = fy0 + 4.f;
         const uint2 rng = ranges[(size_t)c * Tn + tile];
         const int n_total = (int)(rng.y - rng.x);
         const int seg_begin = sgm * kSeg, seg_end = min(n_total, seg_begin + kSeg);
@@ -543,17 +694,16 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
                                                                          // where the slots behind a short batch's end hold whatever LDS held)
                 const float4 a = sh_rec[3u * jj], b = sh_rec[3u * jj + 1u];
                 const BwdSplat sp{b.y, b.z, b.w, sh_rec[3u * jj + 2u].x};
-                const float dxl = a.x - fx0;
-                const v2f dx = {dxl, dxl - 4.f};
-                const v2f axx = a.z * dx * dx + b.y, bx = a.w * dx;
+                const v2f dx = (a.x - fxl) - qoff;
+                const LpTerms lt = lp_terms(a.z, a.w, b.y, dx);
                 BwdAcc A;
                 {
                     const float dy = a.y - fy0;
-                    bwd_pair<true>(sp, (b.x * dy + bx) * dy + axx, dx, dy, (int)j, P0, A);
+                    bwd_pair<true>(sp, lp_at(lt, b.x, dy), dx, dy, (int)j, P0, A);
                 }
                 {
                     const float dy = a.y - fy1;
-                    bwd_pair<false>(sp, (b.x * dy + bx) * dy + axx, dx, dy, (int)j, P1, A);
+                    bwd_pair<false>(sp, lp_at(lt, b.x, dy), dx, dy, (int)j, P1, A);
                 }
                 float s[9] = {add_halves(A.X), add_halves(A.Y), add_halves(A.S2), add_halves(A.S3), add_halves(A.S4), add_halves(A.S5),
                               add_halves(A.S6), add_halves(A.S7), add_halves(A.S8)};

@@ -565,6 +565,23 @@ def test_chunk_sort_paths_agree_and_equal_depths_keep_index_order():
     assert live > 100
 
 
+def test_both_blend_forward_kernels_render_the_same_bits(tmp_path):
+    """csrc/gsr_render.hip has two blend forward kernels (lock step; one 16-lane group per quadrant for chunks of small splats) and
+    the backward recomputes every alpha: all three share one definition of lp with every rounding spelled out, so the kernels must
+    agree bit for bit (slabs of one frame may pick different kernels).  GSR_FWD_GROUPS forces the choice; it is read when the library
+    is loaded, hence the two child processes."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for forced in ("0", "1"):
+        out = str(tmp_path / f"fwd{forced}.npy")
+        env = dict(os.environ, GSR_FWD_GROUPS=forced)
+        subprocess.run([sys.executable, os.path.join(root, "tools", "fwd_kernels_cmp.py"), "fix", out], check=True, env=env, timeout=300)
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all() and outs[0].std() > 0.01
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_slab_renders_tile_the_image_and_gradients_sum():
     """Tile-row slabs (multi-GPU sharding) on one device: slabs reproduce the full render
     bit-for-bit, and slab screen-space gradients sum to the full ones."""
