@@ -239,7 +239,8 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
     const uint2 rng = ranges_c[tile];
     const int lane = threadIdx.x;
     const int px0 = tx * GSR_TILE + lane_px(lane), py0 = ty * GSR_TILE + lane_py(lane);       // the lane's pixel in quadrant 0
-    const float fx0 = (float)px0, fy0 = (float)py0, fy1 = fy0 + 8.f;
+    const float fy0 = (float)py0, fy1 = fy0 + 8.f;
+    const v2f fxv = {(float)px0, (float)(px0 + 8)};
     const size_t N = (size_t)f.W * f.H;
 
     FwdPair P0, P1;
@@ -291,8 +292,7 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd(FrameK f, i
             const float4 a = sh_rec[3 * j], b = sh_rec[3 * j + 1];
             const float cbl = sh_rec[3 * j + 2].x;
             const int contributor = enc_base | (base + j + 1);
-            const float dxl = a.x - fx0;
-            const v2f dx = {dxl, dxl - 8.f};
+            const v2f dx = a.x - fxv;                                 // one subtraction from the pixel's x (all three blend kernels)
             const LpTerms lt = lp_terms(a.z, a.w, b.y, dx);
             if (m & 3u) {
                 const float dy = a.y - fy0;
@@ -369,10 +369,7 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd_groups(Fram
     const int lane = threadIdx.x, grp = lane >> 4, gi = lane & 15;
     const int lx = gi & 3, ly = gi >> 2;                                                  // inside the quadrant; the other pixels are 4 further
     const int px0 = tx * GSR_TILE + (grp & 1) * 8 + lx, py0 = ty * GSR_TILE + (grp >> 1) * 8 + ly;
-    // dx is formed exactly as k_render_fwd forms it - (x_splat - x of the pixel's twin in the LEFT quadrant) - 8 for a right quadrant -
-    // so that the two kernels (and the backward) agree on every pixel's alpha bit for bit
-    const v2f fxl = {(float)(tx * GSR_TILE + lx), (float)(tx * GSR_TILE + lx + 4)};
-    const float qoff = (grp & 1) ? 8.f : 0.f;
+    const v2f fxv = {(float)px0, (float)(px0 + 4)};
     const float fy0 = (float)py0, fy1 = fy0 + 4.f;
     const size_t N = (size_t)f.W * f.H;
     const unsigned grp_shift = 8u * (unsigned)grp;
@@ -430,7 +427,7 @@ __global__ __launch_bounds__(kWave, GSR_FWD_WAVES) void k_render_fwd_groups(Fram
             const float4 a = sh_rec[3u * jj], b = sh_rec[3u * jj + 1u];
             const float cbl = sh_rec[3u * jj + 2u].x;
             const int contributor = enc_base | (int)((unsigned)base + jj + 1u);
-            const v2f dx = (a.x - fxl) - qoff;
+            const v2f dx = a.x - fxv;
             const LpTerms lt = lp_terms(a.z, a.w, b.y, dx);
             {
                 const float dy = a.y - fy0;
@@ -620,10 +617,9 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
         const int ty = tile / f.Gx, tx = tile - ty * f.Gx;
         const int lx = gi & 3, ly = gi >> 2;                                    // inside the quadrant; the other pixels are 4 further
         const int px0 = tx * GSR_TILE + (grp & 1) * 8 + lx, py0 = ty * GSR_TILE + (grp >> 1) * 8 + ly;
-        // dx exactly as the forward forms it: (x_splat - x of the pixel's twin in the LEFT quadrant) - 8 for a right quadrant; dy is one
-        // subtraction from the pixel's y either way: every pixel's lp, alpha and transmittance are the forward's, bit for bit
-        const v2f fxl = {(float)(tx * GSR_TILE + lx), (float)(tx * GSR_TILE + lx + 4)};
-        const float qoff = (grp & 1) ? 8.f : 0.f;
+        // dx and dy are one subtraction from the pixel's coordinate, as in the forward kernels: every pixel's lp, alpha and transmittance
+        // are the forward's, bit for bit
+        const v2f fxv = {(float)px0, (float)(px0 + 4)};
         const float fy0 = (float)py0, fy1 = fy0 + 4.f;
         const uint2 rng = ranges[(size_t)c * Tn + tile];
         const int n_total = (int)(rng.y - rng.x);
@@ -694,7 +690,7 @@ __global__ __launch_bounds__(kWave, GSR_BWD_WAVES) void k_render_bwd(FrameK f, c
                                                                          // where the slots behind a short batch's end hold whatever LDS held)
                 const float4 a = sh_rec[3u * jj], b = sh_rec[3u * jj + 1u];
                 const BwdSplat sp{b.y, b.z, b.w, sh_rec[3u * jj + 2u].x};
-                const v2f dx = (a.x - fxl) - qoff;
+                const v2f dx = a.x - fxv;
                 const LpTerms lt = lp_terms(a.z, a.w, b.y, dx);
                 BwdAcc A;
                 {
