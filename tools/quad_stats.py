@@ -43,7 +43,8 @@ for k in range(5):
 # cost models (cycles per wave): lockstep = per entry 200 + 174 per half; groups = per step 530, steps of a batch = max over quadrants
 HEAD, HALF, STEP = float(os.environ.get("HEAD", 200)), float(os.environ.get("HALF", 174)), float(os.environ.get("STEP", 530))
 lock = ((m > 0) * HEAD + halves[m] * HALF).sum()
-batch = tile_of * 4096 + pos // 64
+BATCH_N = int(os.environ.get("BATCH_N", 64))
+batch = tile_of * 4096 + pos // BATCH_N
 ub, inv = np.unique(batch, return_inverse=True)
 cnt = np.stack([np.bincount(inv, weights=((m >> g) & 1).astype(float), minlength=len(ub)) for g in range(4)], 1)
 steps = cnt.max(1)
