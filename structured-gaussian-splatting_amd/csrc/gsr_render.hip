@@ -2,10 +2,11 @@
 // per-Gaussian reduction of the backward's instance rows.  Spec: SURVEY A.8 / A.9.
 //
 // MI355X mapping ("one wave, one tile"):
-//   * forward: a 16x16 binning tile is blended by ONE wave64; lane l owns the pixel (l & 7, l >> 3) of each of the tile's
-//     four 8x8 QUADRANTS, so "can this splat reach quadrant k at all" is wave-uniform and clear quadrants are
-//     skipped with scalar branches (sub-tile culling); no workgroup barrier exists anywhere in the blend loop,
-//     and early termination is a wave ballot per quadrant.
+//   * forward: a 16x16 binning tile is blended by ONE wave64.  Chunks of large splats (k_render_fwd): lane l owns the pixel
+//     (l & 7, l >> 3) of each of the tile's four 8x8 QUADRANTS, so "can this splat reach quadrant k at all" is wave-uniform and
+//     clear quadrants are skipped with scalar branches (sub-tile culling); early termination is a wave ballot per quadrant.
+//     Chunks of small splats (k_render_fwd_groups): the backward's mapping, one 16-lane group per quadrant, each walking its own
+//     entries.  The two render the same bits.  No workgroup barrier exists anywhere in the blend loops.
 //   * splat records (48 B: xy, conic, opacity, rgb) are gathered 64 at a time, one per lane, staged in
 //     LDS and read back as broadcasts (ds_read_b128).
 //   * backward: FRONT TO BACK, in independent work units of kSeg list entries (gsr_internal.h: kSeg, UnitLists) that start from the
@@ -68,12 +69,12 @@ __device__ __forceinline__ int wave_max_uniform(int v)
 #endif
 typedef float v2f __attribute__((ext_vector_type(2)));      // packed-fp32 operand: the lane's two pixels of a pair
 
-// Pixel mapping of the FORWARD ("one wave, one tile", QUADRANT-major; the backward has its own, see k_render_bwd): lane l owns the
-// pixel (l & 7, l >> 3) of each of the tile's four 8x8 quadrants.  Whether a splat can reach a quadrant at all (quadrant_mask_q: the exact alpha >= 1/255 bound on the 8x8
-// pixel rectangle) is then WAVE-UNIFORM: a batch's staging lane computes the 4-bit mask with its record, and the blend
-// loops skip clear quadrants with scalar branches.  A 2-3 px splat reaches one or two quadrants of a tile, not four.
-// The two quadrants of a pair share dy and differ by 8 in dx: when both are wanted they run as packed fp32 (v_pk_fma_f32
-// issues two FMAs in the cycles of 1.2 plain ones on gfx950: profiles/valu_microbench), otherwise the wanted one runs scalar.
+// Pixel mapping of k_render_fwd ("one wave, one tile", QUADRANT-major; the group kernels have their own, see k_render_bwd): lane l owns
+// the pixel (l & 7, l >> 3) of each of the tile's four 8x8 quadrants.  Whether a splat can reach a quadrant at all (quadrant_mask_q: the
+// exact alpha >= 1/255 bound on the 8x8 pixel rectangle) is then WAVE-UNIFORM: the 4-bit mask travels with the tile list's entry, and the
+// blend loop skips clear quadrants with scalar branches.  A 2-3 px splat reaches one or two quadrants of a tile, not four.
+// The two quadrants of a pair share dy and differ by 8 in dx: they run as packed fp32 (v_pk_fma_f32 issues two FMAs in the cycles
+// of 1.2 plain ones on gfx950: profiles/valu_microbench).
 __device__ __forceinline__ int lane_px(int lane) { return lane & 7; }
 __device__ __forceinline__ int lane_py(int lane) { return lane >> 3; }
 
