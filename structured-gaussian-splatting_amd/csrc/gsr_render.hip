@@ -800,16 +800,8 @@ __global__ __launch_bounds__(kRedBlock) void k_reduce_rows(int r_begin, int n_ra
         a1.x += __shfl_xor(a1.x, off); a1.y += __shfl_xor(a1.y, off); a1.z += __shfl_xor(a1.z, off); a1.w += __shfl_xor(a1.w, off);
         a8 += __shfl_xor(a8, off);
     }
-    if constexpr (kRedGroup >= 4) {
-        if (live && (cnt || write_empty) && sub < 3) {
-            screen[3 * (size_t)g + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : make_float4(a8, 0.f, 0.f, 0.f));
-        }
-    } else {
-        if (live && (cnt || write_empty)) {              // two lanes per Gaussian: lane 0 stores two of the three words
-            screen[3 * (size_t)g + sub] = sub == 0 ? a0 : a1;
-            if (sub == 0) screen[3 * (size_t)g + 2] = make_float4(a8, 0.f, 0.f, 0.f);
-        }
-    }
+    if (live && (cnt || write_empty) && sub < 3)
+        screen[3 * (size_t)g + sub] = sub == 0 ? a0 : (sub == 1 ? a1 : make_float4(a8, 0.f, 0.f, 0.f));
 }
 
 // One launch per depth chunk that ran, each with its own lanes-per-Gaussian: a whole wave where the chunk's Gaussians own many
@@ -832,14 +824,10 @@ int launch_reduce_rows(const FrameK &f, const gsr_frame_plan &plan, const GeomWS
         const bool filtered = (plan.chunks_filtered >> c) & 1;
         const long long avg = plan.chunk_instances_max[c] / (long long)(r1 - r0);
         const bool wide = !filtered && avg >= 48;
-        // (two lanes per Gaussian for small splats, measured: 89 us against 81 at cfg3n, 352 against 374 at cfg5n — not used)
-        const bool narrow = false;
-        const long long threads = (long long)(r1 - r0) * (wide ? 64 : narrow ? 2 : 8);
+        // (two lanes per Gaussian for small splats, measured: 89 us against 81 at cfg3n, 352 against 374 at cfg5n — not kept)
+        const long long threads = (long long)(r1 - r0) * (wide ? 64 : 8);
         const dim3 grid((unsigned)((threads + kRedBlock - 1) / kRedBlock));
-        if (narrow)
-            hipLaunchKernelGGL(k_reduce_rows<2>, grid, dim3(kRedBlock), 0, s, r0, r1, gw.order, gw.cnt_open, gw.row_begin,
-                               bw.row_valid, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
-        else if (wide)
+        if (wide)
             hipLaunchKernelGGL(k_reduce_rows<64>, grid, dim3(kRedBlock), 0, s, r0, r1, gw.order, gw.cnt_open, gw.row_begin,
                                bw.row_valid, reinterpret_cast<const float4 *>(bw.grad_rows), reinterpret_cast<float4 *>(screen_grads), write_empty);
         else
