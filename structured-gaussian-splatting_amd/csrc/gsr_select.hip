@@ -524,13 +524,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
     __shared__ uint32_t sh_wave[kSmallThreads / kWave];
     __shared__ uint32_t sh_max;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t key[kSmallPer], bkt[kSmallPer], slot[kSmallPer];
+    // (a key's bucket is recomputed where it is needed, and the keys' places inside their buckets - used only when no bucket holds more
+    // than kBucketMax = 32 keys - are kept as bytes, four to a register: 28 registers fewer than three full arrays)
+    uint32_t key[kSmallPer], slot4[(kSmallPer + 3) / 4];
     for (int j = threadIdx.x; j < kBuckets; j += kSmallThreads) bcnt[j] = 0;
     if (threadIdx.x == 0) sh_max = force_radix ? 0xFFFFFFFFu : 0u;
 #pragma unroll
     for (int j = 0; j < kSmallPer; ++j) {                        // coalesced: the partition left keys and tile counts by position
         const int e = threadIdx.x + j * kSmallThreads;
-        key[j] = 0xFFFFFFFFu; bkt[j] = 0; slot[j] = 0;
+        key[j] = 0xFFFFFFFFu;
+        if ((j & 3) == 0) slot4[j >> 2] = 0;
         if (e < n) {
             key[j] = pos_key[r0 + e];
             if constexpr (kStage) { sg[e] = order[r0 + e]; st[e] = pos_tiles[r0 + e]; }
@@ -538,13 +541,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
     }
     __syncthreads();
     const int bshift = bits > kBucketBits ? bits - kBucketBits : 0;
+    auto bucket_of = [&](uint32_t k) { const uint32_t b = k >> bshift; return b < (uint32_t)kBuckets ? b : (uint32_t)kBuckets - 1u; };
 #pragma unroll
     for (int j = 0; j < kSmallPer; ++j) {
         const int e = threadIdx.x + j * kSmallThreads;
         if (e < n) {
-            const uint32_t b = key[j] >> bshift;
-            bkt[j] = b < (uint32_t)kBuckets ? b : (uint32_t)kBuckets - 1u;
-            slot[j] = atomicAdd(&bcnt[bkt[j]], 1u);
+            slot4[j >> 2] |= min(atomicAdd(&bcnt[bucket_of(key[j])], 1u), 255u) << (8 * (j & 3));
         }
     }
     __syncthreads();
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_chunk_sort_small(int n, uint3
 #pragma unroll
         for (int j = 0; j < kSmallPer; ++j) {
             const int e = threadIdx.x + j * kSmallThreads;
-            if (e < n) sc[(uint32_t)bofs[bkt[j]] + slot[j]] = ((unsigned long long)key[j] << 32) | (unsigned long long)e;
+            if (e < n) sc[(uint32_t)bofs[bucket_of(key[j])] + ((slot4[j >> 2] >> (8 * (j & 3))) & 255u)] = ((unsigned long long)key[j] << 32) | (unsigned long long)e;
         }
         __syncthreads();
         // RANK sort inside the buckets, one position per lane: a position's bucket spans at most kBucketMax neighbours on
